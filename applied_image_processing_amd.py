@@ -1,0 +1,14 @@
+"""Import shim: the package directory is ``applied-image-processing_amd/`` (a hyphen is not a
+legal Python identifier), so ``import applied_image_processing_amd`` lands here and this module
+replaces itself in ``sys.modules`` with the real package loaded from that directory."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "applied-image-processing_amd")
+_spec = importlib.util.spec_from_file_location(
+    __name__, os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir]
+)
+_pkg = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _pkg
+_spec.loader.exec_module(_pkg)

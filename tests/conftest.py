@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def weights():
+    """Seed-0 synthetic weights as torch CPU state_dicts (reference key layout)."""
+    import applied_image_processing_amd.synth as synth
+
+    return synth.to_torch(synth.vgg_state_dict(0, full=False)), synth.to_torch(synth.decoder_state_dict(0))
+
+
+def golden(name):
+    import numpy as np
+
+    return np.load(os.path.join(GOLDEN, name))
