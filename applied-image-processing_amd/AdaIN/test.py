@@ -1,0 +1,308 @@
+"""AdaIN inference entry points — same names, positional order, defaults and return types as the
+reference's Style_3DGS/AdaIN/test.py (file:line cited per function), running on hand-written
+gfx950 kernels through the C ABI (include/adain_hip.h).  A GPU is required: there is no CPU path.
+
+Differences that are deliberate and invisible to callers:
+  * weights are loaded from disk once per (path, mtime) and packed once, not on every call
+    (the reference reloads 94 MB per call, test.py:183-184);
+  * torchvision / cv2 are not needed: ``test_transform`` and ``save_image`` are restated on PIL with
+    torchvision 0.13 semantics (environment.yml:20);
+  * the MiDaS depth estimator (test.py:84-116) is a pluggable provider (``set_depth_provider``):
+    ``torch.hub`` needs the network; a caller-supplied callable or a precomputed depth map
+    (``depth_map=`` keyword of ``adain_inference``) replaces it offline.
+"""
+from pathlib import Path
+
+import numpy as np
+import torch
+from PIL import Image
+
+from .. import runtime as rt
+from . import net
+from .function import adaptive_instance_normalization, calc_mean_std, coral  # noqa: F401
+
+
+# ---------------------------------------------------------------------------------------------------------
+# test_transform (test.py:16-24): Resize(size) -> [CenterCrop(size)] -> ToTensor, on PIL
+# ---------------------------------------------------------------------------------------------------------
+def _resize_size(w, h, size):
+    # torchvision.transforms.Resize(int): shorter side -> size, longer side -> int(size * long / short)
+    short, long_ = (w, h) if w <= h else (h, w)
+    if short == size:
+        return w, h
+    new_short, new_long = size, int(size * long_ / short)
+    return (new_short, new_long) if w <= h else (new_long, new_short)
+
+
+def _center_crop(img, size):
+    w, h = img.size
+    if w < size or h < size:  # torchvision pads with 0 first
+        pad_l, pad_t = max((size - w) // 2, 0), max((size - h) // 2, 0)
+        canvas = Image.new(img.mode, (max(w, size), max(h, size)))
+        canvas.paste(img, (pad_l, pad_t))
+        img = canvas
+        w, h = img.size
+    top, left = int(round((h - size) / 2.0)), int(round((w - size) / 2.0))
+    return img.crop((left, top, left + size, top + size))
+
+
+def _to_tensor(img):
+    # torchvision ToTensor: HWC uint8 -> CHW float32 / 255
+    if img.mode in ("I", "I;16", "F"):
+        arr = np.array(img, dtype=np.float32)[:, :, None]
+        return torch.from_numpy(arr.transpose(2, 0, 1).copy())
+    if img.mode == "1":
+        img = img.convert("L")
+    arr = np.asarray(img, dtype=np.uint8)
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    return torch.from_numpy(arr.transpose(2, 0, 1).copy()).float().div(255)
+
+
+def test_transform(size, crop):
+    def transform(img):
+        if size != 0:
+            img = img.resize(_resize_size(img.size[0], img.size[1], size), Image.BILINEAR)
+        if crop:
+            img = _center_crop(img, size)
+        return _to_tensor(img)
+
+    return transform
+
+
+test_transform.__test__ = False  # not a pytest test
+
+
+def save_image(tensor, path):
+    """torchvision.utils.save_image for one image (test.py:243-244): x*255 + 0.5, clamp, uint8, PIL save.
+    The quantisation runs on the GPU (adain_quantize_u8)."""
+    if tensor.dim() == 3:
+        tensor = tensor.unsqueeze(0)
+    u8 = rt.quantize_u8(tensor.float()[:1])[0].cpu().numpy()
+    Image.fromarray(u8[:, :, 0] if u8.shape[2] == 1 else u8).save(str(path))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# weights: loaded once per (path, mtime, size)
+# ---------------------------------------------------------------------------------------------------------
+_loaded = {}
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise rt.AdainHipError("no GPU visible: the AdaIN path runs only on the MI355X HIP kernels (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _load_into(module, path, tag):
+    p = Path(path)
+    st = p.stat()
+    key = (tag, str(p.resolve()), st.st_mtime_ns, st.st_size)
+    if _loaded.get(tag) != key:
+        module.load_state_dict(torch.load(str(p), map_location="cpu"))
+        _loaded[tag] = key
+
+
+# ---------------------------------------------------------------------------------------------------------
+def get_style_embeddings(
+    style_img,
+    vgg_str="Style_3DGS/AdaIN/models/vgg_normalised.pth",
+    style_size=512,
+    crop=False,
+):
+    """relu4_1 features of the style image, [1,512,h,w] on the GPU (test.py:27-49)."""
+    device = _device()
+    vgg = net.vgg
+    vgg.eval()
+    _load_into(vgg, vgg_str, "vgg")
+    vgg.to(device)
+
+    style_tf = test_transform(style_size, crop)
+    style = style_tf(style_img)
+    style = style.to(device).unsqueeze(0)
+
+    # might have alpha channel
+    if style.shape[1] == 4:
+        style = style[:, :3, :, :]
+    return vgg(style)
+
+
+def style_transfer(vgg, decoder, content, style, depth_map, alpha=1.0, offset=0.15, prominence=20):
+    """Depth-aware transfer (test.py:52-71): decoder(AdaIN*(1-P) + content_f*P).  ``alpha`` is asserted
+    but unused, as in the reference."""
+    assert 0.0 <= alpha <= 1.0
+    assert 0.0 <= offset <= 1.0
+    content_f = vgg(content)
+
+    # might have alpha channel
+    if style.shape[1] == 4:
+        style = style[:, :3, :, :]
+    style_f = vgg(style)
+
+    # compute P
+    _, _, Hc, Wc = content_f.shape
+    P = compute_stylization_strength_map(depth_map, (Hc, Wc), offset, prominence)
+    feat = _adain_blend(content_f, style_f, pmap=P)
+    return decoder(feat)
+
+
+def style_transfer_simple(vgg, decoder, content, style, alpha=0.5):
+    """decoder(AdaIN*alpha + content_f*(1-alpha)) (test.py:74-81)."""
+    assert 0.0 <= alpha <= 1.0
+    content_f = vgg(content)
+    style_f = vgg(style)
+    feat = _adain_blend(content_f, style_f, alpha=alpha)
+    return decoder(feat)
+
+
+def _adain_blend(content_f, style_f, alpha=None, pmap=None):
+    """Fused adaptive_instance_normalization + feature blend (one pass over the feature map)."""
+    from .function import _layout, _like
+
+    assert (content_f.size()[:2] == style_f.size()[:2])
+    N, C = content_f.size()[:2]
+    s_mean, s_std = calc_mean_std(style_f)
+    c_mean, c_std = calc_mean_std(content_f)
+    view, nhwc = _layout(content_f)
+    args = (view, nhwc, c_mean.view(N, C), c_std.view(N, C), s_mean.view(N, C), s_std.view(N, C))
+    out = rt.blend_pmap(*args, pmap) if pmap is not None else rt.blend_alpha(*args, alpha)
+    return _like(out, nhwc)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# depth provider (reference: midas_depth_map_est, test.py:84-116)
+# ---------------------------------------------------------------------------------------------------------
+_depth_provider = None
+
+
+def set_depth_provider(fn):
+    """``fn(PIL.Image | np.ndarray) -> torch.Tensor [H0,W0]`` (proximity / inverse depth).  None restores the
+    default (MiDaS_small through torch.hub, which needs network access)."""
+    global _depth_provider
+    _depth_provider = fn
+
+
+def midas_depth_map_est(img):
+    if _depth_provider is not None:
+        return _depth_provider(img)
+    device = _device()
+    # default provider, as the reference: MiDaS_small via torch.hub (network); its BGR<->RGB swap
+    # (test.py:101-102) is reproduced without cv2 by reversing the channel axis.
+    midas = torch.hub.load("intel-isl/MiDaS", "MiDaS_small")
+    midas_transforms = torch.hub.load("intel-isl/MiDaS", "transforms")
+    midas.to(device)
+    midas.eval()
+    transform = midas_transforms.small_transform
+    if isinstance(img, Image.Image):
+        img = np.array(img)
+    if img.ndim == 3 and img.shape[-1] == 3:
+        img = img[:, :, ::-1].copy()
+    input_batch = transform(img).to(device)
+    with torch.no_grad():
+        prediction = midas(input_batch)
+        prediction = torch.nn.functional.interpolate(
+            prediction.unsqueeze(1), size=img.shape[:2], mode="bicubic", align_corners=False
+        ).squeeze()
+    return prediction
+
+
+def compute_stylization_strength_map(depth_map, encoder_size, offset=0.15, prominence=20):
+    """Proximity map -> stylisation strength P [1,1,Hc,Wc] (test.py:119-150), one HIP call chain and no
+    host synchronisation (the reference's ``if max_val > min_val`` runs on the device)."""
+    Hc, Wc = encoder_size
+    if not isinstance(depth_map, torch.Tensor):
+        depth_map = torch.as_tensor(np.asarray(depth_map))
+    depth_map = depth_map.to(device=_device(), dtype=torch.float32)
+    return rt.strength_map(depth_map, int(Hc), int(Wc), offset, prominence)
+
+
+# ---------------------------------------------------------------------------------------------------------
+def adain_inference(
+    content_img,
+    style_img,
+    vgg_str="Style_3DGS/AdaIN/models/vgg_normalised.pth",
+    decoder_str="Style_3DGS/AdaIN/models/decoder.pth",
+    depth_offset=0.5,
+    depth_prominence=20,
+    content_size=512,
+    style_size=512,
+    alpha=0.5,
+    crop=False,
+    save_ext=".jpg",
+    output="output",
+    file_name="test",
+    preserve_color=False,
+    content_mask=None,
+    use_depth=False,
+    depth_map=None,
+):
+    """Stylise one content image with one style image and save it; returns the output ``Path``
+    (test.py:153-247).  ``depth_map`` (extra, keyword-only in practice) supplies a precomputed proximity
+    map [H0,W0] for ``use_depth=True`` instead of calling the depth provider."""
+    device = _device()
+
+    output_dir = Path(output)
+    output_dir.mkdir(exist_ok=True, parents=True)
+
+    decoder = net.decoder
+    vgg = net.vgg
+    decoder.eval()
+    vgg.eval()
+    _load_into(decoder, decoder_str, "decoder")
+    _load_into(vgg, vgg_str, "vgg")
+    vgg.to(device)
+    decoder.to(device)
+
+    content_tf = test_transform(content_size, crop)
+    style_tf = test_transform(style_size, crop)
+
+    # process one content and one style
+    if type(content_img) == str:
+        content_img = Image.open(content_img)
+    if type(style_img) == str:
+        style_img = Image.open(str(style_img))
+
+    content = content_tf(content_img)
+    style = style_tf(style_img)
+    if preserve_color:
+        style = coral(style, content)
+    style = style.to(device).unsqueeze(0)
+    content = content.to(device).unsqueeze(0)
+
+    with torch.no_grad():
+        if use_depth:
+            depth_map_est = depth_map if depth_map is not None else midas_depth_map_est(content_img)
+            output_img = style_transfer(vgg, decoder, content, style, depth_map_est, alpha, depth_offset, depth_prominence)
+        else:
+            output_img = style_transfer_simple(vgg, decoder, content, style, alpha)
+
+        if content_mask is not None:
+            stylized_tensor = composite_with_mask(content, output_img, content_mask)
+        else:
+            stylized_tensor = output_img
+
+    if stylized_tensor.shape[1] == 4:  # If it has 4 channels (RGBA)
+        stylized_tensor = stylized_tensor[:, :3, :, :]
+
+    output_path = output_dir / f"{file_name}{save_ext}"
+    save_image(stylized_tensor, str(output_path))
+    print(f"Image saved to {output_path}")
+
+    return output_path
+
+
+def composite_with_mask(content, output_img, content_mask):
+    """The content-mask composite of adain_inference (test.py:222-236): mask -> float -> unsqueeze(0) ->
+    nearest resize to the content size; output bilinear-resized to the content size;
+    content*(1-m) + output*m."""
+    if isinstance(content_mask, torch.Tensor):
+        mask_tensor = content_mask.to(device=content.device).float()
+    else:
+        mask_tensor = torch.from_numpy(np.ascontiguousarray(content_mask)).float().to(content.device)
+    mask_tensor = mask_tensor.unsqueeze(0)
+    size = tuple(content.shape[-2:])
+    mask_tensor = rt.resize_nearest(mask_tensor, size)
+    output_img = rt.resize_bilinear(output_img, size)
+    if content.shape[1] != output_img.shape[1]:
+        raise ValueError(f"content has {content.shape[1]} channels but the stylised output has {output_img.shape[1]}")
+    return rt.mask_composite(content.contiguous(), output_img, mask_tensor)

@@ -1,0 +1,64 @@
+"""Builds the gfx950 shared library in-tree: ``applied-image-processing_amd/libadain_hip.so``.
+
+hipcc cross-compiles without a GPU.  Objects are rebuilt only when a source or header is newer.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+INC = os.path.join(os.path.dirname(PKG), "include")
+LIB = os.path.join(PKG, "libadain_hip.so")
+SOURCES = ["conv.hip", "stats.hip", "pixel.hip", "api.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    c = os.environ.get("HIPCC")
+    if c:
+        return c
+    return "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(INC, "adain_hip.h")]
+    hipcc = _hipcc()
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            jobs.append([hipcc] + FLAGS + ["-I", INC, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _newer(LIB, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

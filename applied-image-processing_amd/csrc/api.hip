@@ -1,0 +1,283 @@
+// extern "C" boundary (include/adain_hip.h) and the encoder / decoder layer schedules.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/adain_hip.h"
+#include "common.h"
+
+namespace adain {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// Layer tables.  Encoder = net.vgg[:31] (reference net.py:38-69): conv0+conv1_1 folded ("first"), then
+// 8 generic 3x3 convs; the ceil-mode max-pools in front of conv2_1, conv3_1, conv4_1 are fused into those
+// convs' gathers.  Decoder = net.decoder (net.py:6-36): 8 generic convs (the nearest-2x upsamples in front
+// of the 2nd, 6th and 8th are fused into their gathers) + the 64->3 "last" conv.
+struct Layer { int cin, cout, src; };
+static const Layer ENC[8] = {{64, 64, SRC_DIRECT},  {64, 128, SRC_POOL2},  {128, 128, SRC_DIRECT}, {128, 256, SRC_POOL2},
+                             {256, 256, SRC_DIRECT}, {256, 256, SRC_DIRECT}, {256, 256, SRC_DIRECT}, {256, 512, SRC_POOL2}};
+static const Layer DEC[8] = {{512, 256, SRC_DIRECT}, {256, 256, SRC_UP2X},   {256, 256, SRC_DIRECT}, {256, 256, SRC_DIRECT},
+                             {256, 128, SRC_DIRECT}, {128, 128, SRC_UP2X},   {128, 64, SRC_DIRECT},  {64, 64, SRC_UP2X}};
+
+static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
+constexpr size_t FIRST_W = 2 * 4 * 64 * 4, FIRST_B = 64, LAST_W = 4 * 9 * 4 * 4 * 3, LAST_B = 3;
+
+// packed layout: [first w][first b] then per generic layer [w][b], every block 256-B aligned
+static size_t enc_offsets(size_t* w_off, size_t* b_off, size_t* first_b) {
+    size_t o = 0;
+    o += align64(FIRST_W);
+    *first_b = o;
+    o += align64(FIRST_B);
+    for (int i = 0; i < 8; ++i) {
+        w_off[i] = o;
+        o += align64((size_t)ENC[i].cin * ENC[i].cout * 9);
+        b_off[i] = o;
+        o += align64(ENC[i].cout);
+    }
+    return o;
+}
+static size_t dec_offsets(size_t* w_off, size_t* b_off, size_t* last_w, size_t* last_b) {
+    size_t o = 0;
+    for (int i = 0; i < 8; ++i) {
+        w_off[i] = o;
+        o += align64((size_t)DEC[i].cin * DEC[i].cout * 9);
+        b_off[i] = o;
+        o += align64(DEC[i].cout);
+    }
+    *last_w = o;
+    o += align64(LAST_W);
+    *last_b = o;
+    o += align64(LAST_B);
+    return o;
+}
+
+static int copy_bias(const float* src, float* dst, int n, hipStream_t s) {
+    if (hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        set_error("bias copy failed: %s", hipGetErrorString(hipGetLastError()));
+        return ADAIN_ELAUNCH;
+    }
+    return 0;
+}
+
+static void record(void* const* ev, int i, hipStream_t s) {
+    if (ev && ev[i]) (void)hipEventRecord((hipEvent_t)ev[i], s);
+}
+
+}  // namespace adain
+
+using namespace adain;
+
+#define RET_IF(x) do { int _r = (x); if (_r) return _r; } while (0)
+
+extern "C" {
+
+int adain_abi_version(void) { return ADAIN_ABI_VERSION; }
+const char* adain_last_error(void) { return g_err; }
+
+size_t adain_encoder_packed_floats(void) {
+    size_t w[8], b[8], fb;
+    return enc_offsets(w, b, &fb);
+}
+size_t adain_decoder_packed_floats(void) {
+    size_t w[8], b[8], lw, lb;
+    return dec_offsets(w, b, &lw, &lb);
+}
+
+int adain_encoder_pack(const float* const* w, const float* const* b, float* packed, adain_stream_t stream) {
+    if (!w || !b || !packed) { set_error("encoder_pack: null pointer"); return ADAIN_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    size_t wo[8], bo[8], fb;
+    enc_offsets(wo, bo, &fb);
+    RET_IF(launch_pack_conv_first(w[0], b[0], w[1], b[1], packed, packed + fb, s));
+    for (int i = 0; i < 8; ++i) {
+        RET_IF(launch_pack_conv3x3(w[i + 2], packed + wo[i], ENC[i].cin, ENC[i].cout, s));
+        RET_IF(copy_bias(b[i + 2], packed + bo[i], ENC[i].cout, s));
+    }
+    return 0;
+}
+
+int adain_decoder_pack(const float* const* w, const float* const* b, float* packed, adain_stream_t stream) {
+    if (!w || !b || !packed) { set_error("decoder_pack: null pointer"); return ADAIN_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    size_t wo[8], bo[8], lw, lb;
+    dec_offsets(wo, bo, &lw, &lb);
+    for (int i = 0; i < 8; ++i) {
+        RET_IF(launch_pack_conv3x3(w[i], packed + wo[i], DEC[i].cin, DEC[i].cout, s));
+        RET_IF(copy_bias(b[i], packed + bo[i], DEC[i].cout, s));
+    }
+    RET_IF(launch_pack_conv_last(w[8], packed + lw, s));
+    RET_IF(copy_bias(b[8], packed + lb, 3, s));
+    return 0;
+}
+
+void adain_encoded_size(int h, int w, int* hc, int* wc) {
+    for (int i = 0; i < 3; ++i) { h = (h + 1) / 2; w = (w + 1) / 2; }
+    if (hc) *hc = h;
+    if (wc) *wc = w;
+}
+
+size_t adain_encode_workspace_bytes(int n, int h, int w) {
+    if (n < 1 || h < 1 || w < 1) return 0;
+    return 2 * align64((size_t)n * h * w * 64) * sizeof(float);
+}
+
+int adain_encode(const float* image, float* feat, const float* packed, void* workspace, size_t ws_bytes, int n, int h,
+                 int w, void* const* ev, adain_stream_t stream) {
+    if (!image || !feat || !packed || !workspace) { set_error("encode: null pointer"); return ADAIN_EINVAL; }
+    if (n < 1 || h < 9 || w < 9) {
+        // relu4_1 must be at least 2x2 for the reflection pad in front of conv4_1 (torch raises there too)
+        set_error("encode: image %dx%d too small (needs h, w >= 9)", h, w);
+        return ADAIN_EINVAL;
+    }
+    if (ws_bytes < adain_encode_workspace_bytes(n, h, w)) { set_error("encode: workspace too small"); return ADAIN_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    size_t wo[8], bo[8], fb;
+    enc_offsets(wo, bo, &fb);
+    float* bufA = (float*)workspace;
+    float* bufB = bufA + align64((size_t)n * h * w * 64);
+    record(ev, 0, s);
+    RET_IF(launch_conv_first(image, bufA, packed, packed + fb, n, h, w, s));
+    record(ev, 1, s);
+    const float* cur = bufA;
+    int ch = h, cw = w;
+    for (int i = 0; i < 8; ++i) {
+        ConvArgs a{};
+        a.in = cur;
+        a.out = (i == 7) ? feat : (cur == bufA ? bufB : bufA);
+        a.wpk = packed + wo[i];
+        a.bias = packed + bo[i];
+        a.n = n;
+        a.Hs = ch; a.Ws = cw;
+        if (ENC[i].src == SRC_POOL2) { ch = (ch + 1) / 2; cw = (cw + 1) / 2; }
+        a.H = ch; a.W = cw;
+        a.cin = ENC[i].cin; a.cout = ENC[i].cout;
+        a.relu = 1;
+        RET_IF(launch_conv3x3(a, ENC[i].src, s));
+        record(ev, i + 2, s);
+        cur = a.out;
+    }
+    return 0;
+}
+
+size_t adain_decode_workspace_bytes(int n, int hc, int wc) {
+    if (n < 1 || hc < 1 || wc < 1) return 0;
+    return (align64((size_t)n * hc * wc * 1024) + align64((size_t)n * hc * wc * 4096)) * sizeof(float);
+}
+
+int adain_decode(const float* feat, float* image, const float* packed, void* workspace, size_t ws_bytes, int n, int hc,
+                 int wc, void* const* ev, adain_stream_t stream) {
+    if (!feat || !image || !packed || !workspace) { set_error("decode: null pointer"); return ADAIN_EINVAL; }
+    if (n < 1 || hc < 2 || wc < 2) { set_error("decode: feature map %dx%d too small (needs >= 2x2)", hc, wc); return ADAIN_EINVAL; }
+    if (ws_bytes < adain_decode_workspace_bytes(n, hc, wc)) { set_error("decode: workspace too small"); return ADAIN_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    size_t wo[8], bo[8], lw, lb;
+    dec_offsets(wo, bo, &lw, &lb);
+    // buffer A (1024*hc*wc floats per image) takes the outputs of layers 0,2,4,6; buffer B (4096*hc*wc) of 1,3,5,7
+    float* bufA = (float*)workspace;
+    float* bufB = bufA + align64((size_t)n * hc * wc * 1024);
+    const float* cur = feat;
+    int ch = hc, cw = wc;
+    record(ev, 0, s);
+    for (int i = 0; i < 8; ++i) {
+        ConvArgs a{};
+        a.in = cur;
+        a.out = (i & 1) ? bufB : bufA;
+        a.wpk = packed + wo[i];
+        a.bias = packed + bo[i];
+        a.n = n;
+        a.Hs = ch; a.Ws = cw;
+        if (DEC[i].src == SRC_UP2X) { ch *= 2; cw *= 2; }
+        a.H = ch; a.W = cw;
+        a.cin = DEC[i].cin; a.cout = DEC[i].cout;
+        a.relu = 1;
+        RET_IF(launch_conv3x3(a, DEC[i].src, s));
+        record(ev, i + 1, s);
+        cur = a.out;
+    }
+    RET_IF(launch_conv_last(cur, image, packed + lw, packed + lb, n, ch, cw, s));
+    record(ev, 9, s);
+    return 0;
+}
+
+size_t adain_mean_std_workspace_bytes(int nhwc, int n, int c, int hw) { return mean_std_workspace_bytes(nhwc, n, c, hw); }
+
+int adain_mean_std(const float* feat, int nhwc, int n, int c, int hw, float eps, float* mean, float* std_out, void* workspace,
+                   size_t ws_bytes, adain_stream_t stream) {
+    if (!feat || !mean || !std_out) { set_error("mean_std: null pointer"); return ADAIN_EINVAL; }
+    return launch_mean_std(feat, nhwc, n, c, hw, eps, mean, std_out, workspace, ws_bytes, (hipStream_t)stream);
+}
+
+int adain_blend_alpha(const float* x, int nhwc, int n, int c, int hw, const float* c_mean, const float* c_std,
+                      const float* s_mean, const float* s_std, int style_n, float alpha, float one_minus_alpha, float* out,
+                      adain_stream_t stream) {
+    if (!x || !c_mean || !c_std || !s_mean || !s_std || !out) { set_error("blend_alpha: null pointer"); return ADAIN_EINVAL; }
+    return launch_adain_blend_ex(x, nhwc, n, c, hw, c_mean, c_std, s_mean, s_std, style_n, alpha, one_minus_alpha, nullptr, 1, out,
+                                 (hipStream_t)stream);
+}
+
+int adain_blend_pmap(const float* x, int nhwc, int n, int c, int hw, const float* c_mean, const float* c_std,
+                     const float* s_mean, const float* s_std, int style_n, const float* pmap, int pmap_n, float* out,
+                     adain_stream_t stream) {
+    if (!x || !c_mean || !c_std || !s_mean || !s_std || !out || !pmap) { set_error("blend_pmap: null pointer"); return ADAIN_EINVAL; }
+    return launch_adain_blend_ex(x, nhwc, n, c, hw, c_mean, c_std, s_mean, s_std, style_n, 0.f, 0.f, pmap, pmap_n, out,
+                                 (hipStream_t)stream);
+}
+
+size_t adain_strength_map_workspace_bytes(int hc, int wc) { return strength_map_workspace_bytes(hc, wc); }
+
+int adain_strength_map(const float* depth, int h0, int w0, int hc, int wc, float offset, float prominence, float* pmap,
+                       void* workspace, size_t ws_bytes, adain_stream_t stream) {
+    if (!depth || !pmap) { set_error("strength_map: null pointer"); return ADAIN_EINVAL; }
+    return launch_strength_map(depth, h0, w0, hc, wc, offset, prominence, pmap, workspace, ws_bytes, (hipStream_t)stream);
+}
+
+int adain_resize_bilinear(const float* in, float* out, int planes, int hi, int wi, int ho, int wo, adain_stream_t stream) {
+    if (!in || !out) { set_error("resize_bilinear: null pointer"); return ADAIN_EINVAL; }
+    return launch_resize_bilinear(in, out, planes, hi, wi, ho, wo, (hipStream_t)stream);
+}
+int adain_resize_nearest(const float* in, float* out, int planes, int hi, int wi, int ho, int wo, adain_stream_t stream) {
+    if (!in || !out) { set_error("resize_nearest: null pointer"); return ADAIN_EINVAL; }
+    return launch_resize_nearest(in, out, planes, hi, wi, ho, wo, (hipStream_t)stream);
+}
+int adain_mask_composite(const float* content, const float* stylized, const float* mask, int mask_c, int mask_n, float* out, int n,
+                         int c, int hw, adain_stream_t stream) {
+    if (!content || !stylized || !mask || !out) { set_error("mask_composite: null pointer"); return ADAIN_EINVAL; }
+    return launch_mask_composite(content, stylized, mask, mask_c, mask_n, out, n, c, hw, (hipStream_t)stream);
+}
+int adain_quantize_u8(const float* in, uint8_t* out, int n, int c, int h, int w, adain_stream_t stream) {
+    if (!in || !out) { set_error("quantize_u8: null pointer"); return ADAIN_EINVAL; }
+    return launch_quantize_u8(in, out, n, c, h, w, (hipStream_t)stream);
+}
+int adain_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, adain_stream_t stream) {
+    if (!in || !out) { set_error("nhwc_to_nchw: null pointer"); return ADAIN_EINVAL; }
+    return launch_nhwc_to_nchw(in, out, n, c, hw, (hipStream_t)stream);
+}
+int adain_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, adain_stream_t stream) {
+    if (!in || !out) { set_error("nchw_to_nhwc: null pointer"); return ADAIN_EINVAL; }
+    return launch_nchw_to_nhwc(in, out, n, c, hw, (hipStream_t)stream);
+}
+
+size_t adain_conv3x3_packed_floats(int cin, int cout) { return (size_t)cin * cout * 9; }
+
+int adain_conv3x3_pack(const float* w, float* packed, int cin, int cout, adain_stream_t stream) {
+    if (!w || !packed) { set_error("conv3x3_pack: null pointer"); return ADAIN_EINVAL; }
+    return launch_pack_conv3x3(w, packed, cin, cout, (hipStream_t)stream);
+}
+
+int adain_conv3x3(const float* in, float* out, const float* packed_w, const float* bias, int n, int h, int w, int hs, int ws,
+                  int cin, int cout, int src_mode, int relu, adain_stream_t stream) {
+    if (!in || !out || !packed_w || !bias) { set_error("conv3x3: null pointer"); return ADAIN_EINVAL; }
+    ConvArgs a{};
+    a.in = in; a.out = out; a.wpk = packed_w; a.bias = bias;
+    a.n = n; a.H = h; a.W = w; a.Hs = hs; a.Ws = ws; a.cin = cin; a.cout = cout; a.relu = relu;
+    return launch_conv3x3(a, src_mode, (hipStream_t)stream);
+}
+
+}  // extern "C"

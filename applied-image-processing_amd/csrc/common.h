@@ -1,0 +1,73 @@
+// Shared declarations for the gfx950 AdaIN kernels (internal; the public C ABI is include/adain_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace adain {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// Source-gather modes of the 3x3 convolution's input (fused into the LDS staging):
+//   DIRECT : conceptual input == source tensor
+//   UP2X   : conceptual input == nearest 2x upsample of the source   (decoder, net.py:10,23,30)
+//   POOL2  : conceptual input == MaxPool2d(2,2,ceil_mode=True) of the source (encoder, net.py:46,53,66)
+enum SrcMode { SRC_DIRECT = 0, SRC_UP2X = 1, SRC_POOL2 = 2 };
+
+struct ConvArgs {
+    const float* in;    // NHWC source  [n][Hs][Ws][cin]
+    float* out;         // NHWC output  [n][H][W][cout]
+    const float* wpk;   // packed weights (pack_conv3x3_kernel layout)
+    const float* bias;  // [cout]
+    int n, H, W;        // output (== conceptual input) spatial size
+    int Hs, Ws;         // source spatial size
+    int cin, cout;
+    int relu;
+    int tiles_x, tiles_y;
+};
+
+// thread-local error text for adain_last_error()
+void set_error(const char* fmt, ...);
+
+// launchers (conv.hip)
+int launch_pack_conv3x3(const float* w_oihw, float* packed, int cin, int cout, hipStream_t s);
+int launch_pack_conv_first(const float* w0, const float* b0, const float* w1, const float* b1, float* packed,
+                           float* bias_out, hipStream_t s);
+int launch_pack_conv_last(const float* w, float* packed, hipStream_t s);
+int launch_conv3x3(const ConvArgs& a, int src_mode, hipStream_t s);
+int launch_conv_first(const float* img_nchw, float* out_nhwc, const float* packed, const float* bias, int n, int H,
+                      int W, hipStream_t s);
+int launch_conv_last(const float* in_nhwc, float* out_nchw, const float* packed, const float* bias, int n, int H,
+                     int W, hipStream_t s);
+
+// stats.hip
+int launch_mean_std(const float* feat, int nhwc, int n, int c, int hw, float eps, float* mean, float* std_,
+                    void* workspace, size_t ws_bytes, hipStream_t s);
+size_t mean_std_workspace_bytes(int nhwc, int n, int c, int hw);
+int launch_adain_blend_ex(const float* content, int nhwc, int n, int c, int hw, const float* c_mean,
+                          const float* c_std, const float* s_mean, const float* s_std, int style_n, float alpha,
+                          float one_minus_alpha, const float* pmap, int pmap_n, float* out, hipStream_t s);
+
+// pixel.hip
+int launch_strength_map(const float* depth, int h0, int w0, int hc, int wc, float offset, float prominence,
+                        float* pmap, void* workspace, size_t ws_bytes, hipStream_t s);
+size_t strength_map_workspace_bytes(int hc, int wc);
+int launch_resize_bilinear(const float* in, float* out, int planes, int hi, int wi, int ho, int wo, hipStream_t s);
+int launch_resize_nearest(const float* in, float* out, int planes, int hi, int wi, int ho, int wo, hipStream_t s);
+int launch_mask_composite(const float* content, const float* stylized, const float* mask, int mask_c, int mask_n,
+                          float* out, int n, int c, int hw, hipStream_t s);
+int launch_quantize_u8(const float* in_nchw, uint8_t* out_nhwc, int n, int c, int h, int w, hipStream_t s);
+int launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, hipStream_t s);
+int launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, hipStream_t s);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return -2;
+    }
+    return 0;
+}
+
+}  // namespace adain

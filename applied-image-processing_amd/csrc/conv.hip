@@ -1,0 +1,527 @@
+// gfx950 (CDNA4) convolution kernels for the AdaIN encoder/decoder.
+//
+// Replaces the 29 torch.nn.Conv2d calls of the reference hot path (Style_3DGS/AdaIN/net.py:6-36
+// decoder, :38-69 encoder up to relu4_1) together with the ReflectionPad2d(1) in front of every
+// 3x3 conv, the ReLU behind it, the ceil-mode MaxPool2d(2,2) (net.py:46,53,66) and the nearest 2x
+// Upsample (net.py:10,23,30): all of those are folded into the convolution's LDS staging or
+// epilogue, so none of them round-trips HBM.
+//
+// Data layout in HBM: activations NHWC fp32; images NCHW fp32 at the two ends (reference layout).
+//
+// Main kernel = implicit GEMM on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32):
+//   M = 32 consecutive output pixels of one row, N = 32 output channels, K = 9 taps x Cin.
+//   * A operand: the (TH+2) x 34 reflect-padded input halo of a TH x 32 pixel tile is staged ONCE per
+//     16-channel chunk into LDS and re-used by all 9 taps (a tap is just an LDS address offset, so
+//     every ds_read_b128 uses one base VGPR + an immediate).  Pixel stride in LDS is 20 floats (80 B):
+//     any 16 pixels distinct mod 16 then cover all 64 banks -> conflict-free b128 reads and writes.
+//   * B operand: weights are pre-packed on the device into the exact per-lane fragment order
+//     ([cout/32][cin/16][tap][k-group][lane][4]), so a wave fetches each fragment with ONE fully
+//     coalesced 1 KiB global_load_dwordx4 straight into VGPRs (no LDS, no barrier for B).
+//   * K order inside a group of 8 channels is permuted (lane half h supplies channels 4h..4h+3 of
+//     the group, k-step s uses element s), identically for A and B, so each b128 feeds 4 MFMAs.
+//   fp32 MFMA runs at the fp32 vector rate (64 cycles per 32x32x2), so HBM, L2 and LDS traffic are
+//   far below their limits; the kernel is bound by MFMA issue.
+#include "common.h"
+
+namespace adain {
+
+constexpr int KC = 16;           // input channels per LDS chunk
+constexpr int LSTR = KC + 4;     // LDS pixel stride in floats (80 B)
+constexpr int TW = 32;           // tile width == MFMA M
+constexpr int HW_ = TW + 2;      // halo width
+
+__device__ __forceinline__ int reflect1(int v, int n) {
+    // ReflectionPad2d(1) index map, after clamping to [-1, n] (tiles may overhang the image).
+    v = max(-1, min(v, n));
+    v = v < 0 ? -v : v;
+    return v >= n ? 2 * n - 2 - v : v;
+}
+
+__device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) {
+    f32x4 r;
+    r.x = fmaxf(a.x, b.x); r.y = fmaxf(a.y, b.y); r.z = fmaxf(a.z, b.z); r.w = fmaxf(a.w, b.w);
+    return r;
+}
+
+// Buffer-descriptor loads: 32-bit per-lane byte offset + scalar byte offset, hardware range check
+// (out-of-range reads return 0), no 64-bit address arithmetic in the loop.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(rsrc_t r, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing (runs once per weight set, on the device).
+// ---------------------------------------------------------------------------------------------
+// OIHW [cout][cin][3][3]  ->  [cout/32][cin/16][9][2][64 lanes][4]
+//   lane = j + 32 h ; element s : W[cout = 32 T + j][cin = 16 c + 8 g + 4 h + s][tap]
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ p, int cin, int cout) {
+    const size_t total = (size_t)cin * cout * 9;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int s = r & 3; r >>= 2;
+        const int lane = r & 63; r >>= 6;
+        const int g = r & 1; r >>= 1;
+        const int tap = r % 9; r /= 9;
+        const int nch = cin / KC;
+        const int c = r % nch; r /= nch;
+        const int T = (int)r;
+        const int j = lane & 31, h = lane >> 5;
+        const int co = T * 32 + j, ci = c * KC + g * 8 + h * 4 + s;
+        p[i] = w[((size_t)co * cin + ci) * 9 + tap];
+    }
+}
+
+// conv0 (1x1, 3->3, net.py:39) folded into conv1_1 (3->64, net.py:41): a pointwise conv commutes
+// with reflection padding, so W'[o][c][t] = sum_c' W1[o][c'][t] W0[c'][c] and
+// b'[o] = b1[o] + sum_{c',t} W1[o][c'][t] b0[c'].  K index k = tap*3 + c (27 real, padded to 32).
+// packed: [2 cout tiles][4 groups][64 lanes][4] with k = 8 g + 4 h + s.
+__global__ void pack_conv_first_kernel(const float* __restrict__ w0, const float* __restrict__ b0,
+                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                       float* __restrict__ p, float* __restrict__ bias_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * 4 * 64 * 4) {
+        int r = i;
+        const int s = r & 3; r >>= 2;
+        const int lane = r & 63; r >>= 6;
+        const int g = r & 3; r >>= 2;
+        const int T = r;
+        const int j = lane & 31, h = lane >> 5;
+        const int o = T * 32 + j, k = g * 8 + h * 4 + s;
+        float v = 0.f;
+        if (k < 27) {
+            const int tap = k / 3, c = k % 3;
+            for (int cp = 0; cp < 3; ++cp) v += w1[(o * 3 + cp) * 9 + tap] * w0[cp * 3 + c];
+        }
+        p[i] = v;
+    }
+    if (i < 64) {
+        float b = b1[i];
+        for (int cp = 0; cp < 3; ++cp)
+            for (int t = 0; t < 9; ++t) b += w1[(i * 3 + cp) * 9 + t] * b0[cp];
+        bias_out[i] = b;
+    }
+}
+
+// last decoder conv (64->3, net.py:35): OIHW [3][64][3][3] -> [4 chunks][9 taps][4 quads][4 s][3 cout]
+__global__ void pack_conv_last_kernel(const float* __restrict__ w, float* __restrict__ p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * 9 * 4 * 4 * 3) return;
+    int r = i;
+    const int co = r % 3; r /= 3;
+    const int s = r & 3; r >>= 2;
+    const int q = r & 3; r >>= 2;
+    const int tap = r % 9; r /= 9;
+    const int c = r;
+    const int ci = c * KC + q * 4 + s;
+    p[i] = w[(co * 64 + ci) * 9 + tap];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Halo staging shared by the MFMA kernel and the last-layer kernel.
+// One item = 4 consecutive channels (16 B) of one halo pixel; a thread owns NITEM items.
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int TH, int NTHR>
+struct HaloStager {
+    static constexpr int HH = TH + 2;
+    static constexpr int HALO = HH * HW_;
+    static constexpr int NITEM = (HALO * 4 + NTHR - 1) / NTHR;
+    static constexpr int NSRC = MODE == SRC_POOL2 ? 4 : 1;
+
+    int soff[NITEM];              // BYTE offset of the (first) source pixel inside the image, + 16*quad
+    int dxo[NITEM], dyo[NITEM];   // POOL2 only: byte offsets to the right / lower window element (0 if clipped)
+    f32x4 raw[NITEM][NSRC];
+
+    __device__ __forceinline__ void init(int tid, int ty0, int tx0, int H, int W, int Hs, int Ws, int cin) {
+#pragma unroll
+        for (int k = 0; k < NITEM; ++k) {
+            const int idx = tid + k * NTHR;
+            const int hp = min(idx >> 2, HALO - 1), q = idx & 3;   // surplus items re-read the last pixel
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            int y = reflect1(ty0 + hy - 1, H), x = reflect1(tx0 + hx - 1, W);
+            if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
+            if (MODE == SRC_POOL2) {
+                dxo[k] = (2 * x + 1 < Ws) ? cin * 4 : 0;
+                dyo[k] = (2 * y + 1 < Hs) ? Ws * cin * 4 : 0;
+                y *= 2; x *= 2;
+            } else {
+                dxo[k] = 0; dyo[k] = 0;
+            }
+            soff[k] = ((y * Ws + x) * cin + q * 4) * 4;
+        }
+    }
+    // issue the global loads of one 16-channel chunk (coff_bytes = chunk * 64) into registers
+    __device__ __forceinline__ void load(rsrc_t src, int coff_bytes) {
+#pragma unroll
+        for (int k = 0; k < NITEM; ++k) {
+            raw[k][0] = buf_load4(src, soff[k], coff_bytes);
+            if (MODE == SRC_POOL2) {
+                raw[k][1] = buf_load4(src, soff[k] + dxo[k], coff_bytes);
+                raw[k][2] = buf_load4(src, soff[k] + dyo[k], coff_bytes);
+                raw[k][3] = buf_load4(src, soff[k] + dyo[k] + dxo[k], coff_bytes);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* buf, int tid) {
+#pragma unroll
+        for (int k = 0; k < NITEM; ++k) {
+            const int idx = tid + k * NTHR;
+            f32x4 v = raw[k][0];
+            if (MODE == SRC_POOL2) v = max4(max4(v, raw[k][1]), max4(raw[k][2], raw[k][3]));
+            if (NITEM * NTHR == HALO * 4 || idx < HALO * 4) *(f32x4*)(buf + (idx >> 2) * LSTR + (idx & 3) * 4) = v;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 convolution, implicit GEMM on v_mfma_f32_32x32x2_f32.
+//   block  = WM x WN waves; wave tile = MT rows x 32 px  by  NT x 32 channels
+//   block tile = (WM*MT) rows x 32 px  by  WN*NT*32 channels
+// Software pipeline per wave: weight fragments are prefetched 2 k-groups ahead (3-slot register
+// ring, the stream is linear across chunks), A fragments 1 k-group ahead from LDS; the next
+// chunk's halo travels HBM -> registers during the whole chunk and is written to the other LDS
+// buffer just before the single barrier per chunk.
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma_kernel(ConvArgs a) {
+    constexpr int TH = WM * MT;
+    constexpr int NTHR = WM * WN * 64;
+    using Stager = HaloStager<MODE, TH, NTHR>;
+    constexpr int BUF = Stager::HALO * LSTR;
+    constexpr int NSTEP = 9 * (KC / 8);   // k-groups per chunk (18)
+    static_assert(NSTEP % 3 == 0, "ring slot bookkeeping assumes NSTEP % 3 == 0");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int pt = bid % tiles; bid /= tiles;
+    const int nct = a.cout / (WN * NT * 32);
+    const int ct = bid % nct;
+    const int img = bid / nct;
+    const int tx0 = (pt % a.tiles_x) * TW, ty0 = (pt / a.tiles_x) * TH;
+    const int nchunks = a.cin / KC;
+
+    const rsrc_t src = make_rsrc(a.in + (size_t)img * a.Hs * a.Ws * a.cin, (unsigned)a.Hs * a.Ws * a.cin * 4u);
+    const rsrc_t wsr = make_rsrc(a.wpk, (unsigned)a.cin * a.cout * 36u);
+
+    Stager st;
+    st.init(tid, ty0, tx0, a.H, a.W, a.Hs, a.Ws, a.cin);
+
+    // per-wave weight stream: one 1 KiB record per (chunk, tap, k-group), consumed in order;
+    // the NT channel tiles of a wave are consecutive streams.
+    const int tile_bytes = nchunks * NSTEP * 1024;
+    int wso = ((ct * WN + wn) * NT) * tile_bytes;   // scalar byte offset of the current record (tile 0)
+    const int wvo = lane * 16;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int a_base = ((wm * MT) * HW_ + li) * LSTR + lh * 4;
+
+    f32x4 bq[3][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        bq[0][n] = buf_load4(wsr, wvo, wso + n * tile_bytes);
+        bq[1][n] = buf_load4(wsr, wvo, wso + n * tile_bytes + 1024);
+    }
+
+    st.load(src, 0);
+    st.store(smem, tid);
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const float* sbuf = smem + (c & 1) * BUF + a_base;
+        const bool more = c + 1 < nchunks;
+        if (more) st.load(src, (c + 1) * KC * 4);
+        f32x4 aq[2][MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) aq[0][m] = *(const f32x4*)(sbuf + (m * HW_) * LSTR);
+#pragma unroll
+        for (int k = 0; k < NSTEP; ++k) {
+            if (k + 1 < NSTEP) {
+                const int t = (k + 1) >> 1, g = (k + 1) & 1;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    aq[(k + 1) & 1][m] = *(const f32x4*)(sbuf + ((m + t / 3) * HW_ + (t % 3)) * LSTR + g * 8);
+            }
+            // record k+2 of the stream (runs harmlessly past the tile / buffer end on the last steps:
+            // the descriptor's range check returns 0 there)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bq[(k + 2) % 3][n] = buf_load4(wsr, wvo, wso + n * tile_bytes + (k + 2) * 1024);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[k & 1][m][s], bq[k % 3][n][s], acc[m][n], 0, 0, 0);
+            // keep the prefetch distance: without this fence hipcc sinks the loads of step k+2 down to
+            // their first use and waits vmcnt(0) in front of every MFMA group
+            __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);            // next step's A fragments (LDS) first
+            __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);            // then the weight prefetch
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);   // then this step's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wso += NSTEP * 1024;
+        if (more) st.store(smem + ((c + 1) & 1) * BUF, tid);
+        __syncthreads();
+    }
+
+    // epilogue: bias + ReLU, NHWC store.  C layout of the 32x32 tile: column (lane&31) = channel,
+    // row = (r&3) + 8*(r>>2) + 4*(lane>>5) = pixel; each store instruction writes 2 x 128 B segments.
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int y = ty0 + wm * MT + m;
+        if (y >= a.H) continue;
+        float* __restrict__ orow = a.out + ((size_t)img * a.H + y) * a.W * a.cout;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = ((ct * WN + wn) * NT + n) * 32 + li;
+            const float b = a.bias[co];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = tx0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[m][n][r] + b;
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (x < a.W) orow[(size_t)x * a.cout + co] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// First layer: conv0 (1x1) folded into conv1_1 (3 -> 64), NCHW image in, NHWC out, ReLU.
+// im2col of the 8x32 tile into LDS ([256 px][32 k], stride 36 floats), then 4 k-groups of MFMA.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ img_nchw,
+                                                         float* __restrict__ out, const float* __restrict__ wpk,
+                                                         const float* __restrict__ bias, int H, int W, int tiles_x,
+                                                         int tiles_y) {
+    constexpr int S = 36;
+    __shared__ __attribute__((aligned(16))) float smem[256 * S];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int bid = blockIdx.x;
+    const int tiles = tiles_x * tiles_y;
+    const int pt = bid % tiles;
+    const int img = bid / tiles;
+    const int tx0 = (pt % tiles_x) * 32, ty0 = (pt / tiles_x) * 8;
+    const float* __restrict__ src = img_nchw + (size_t)img * 3 * H * W;
+
+    {
+        const int py = tid >> 5, px = tid & 31;
+        float v[32];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int y = reflect1(ty0 + py + t / 3 - 1, H), x = reflect1(tx0 + px + t % 3 - 1, W);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[t * 3 + c] = src[((size_t)c * H + y) * W + x];
+        }
+#pragma unroll
+        for (int k = 27; k < 32; ++k) v[k] = 0.f;
+        float* d = smem + tid * S;
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) *(f32x4*)(d + k) = f32x4{v[k], v[k + 1], v[k + 2], v[k + 3]};
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 af[2], bf[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) af[m] = *(const f32x4*)(smem + ((wave * 2 + m) * 32 + li) * S + g * 8 + lh * 4);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[n] = *(const f32x4*)(wpk + ((n * 4 + g) * 64 + lane) * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][s], bf[n][s], acc[m][n], 0, 0, 0);
+    }
+
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int y = ty0 + wave * 2 + m;
+        if (y >= H) continue;
+        float* __restrict__ orow = out + ((size_t)img * H + y) * W * 64;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int co = n * 32 + li;
+            const float b = bias[co];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = tx0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (x < W) orow[(size_t)x * 64 + co] = fmaxf(acc[m][n][r] + b, 0.f);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Last layer: 64 -> 3, no ReLU, NHWC in, NCHW image out.  N = 3 would waste 90 % of an MFMA tile and
+// fp32 MFMA has no rate advantage over the vector ALU, so this is a VALU kernel: one thread per
+// output pixel, inputs from the same LDS halo image as the MFMA kernel (conflict-free b128 reads),
+// weights wave-uniform (scalar loads).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                        int H, int W, int tiles_x, int tiles_y) {
+    constexpr int TH = 8, NTHR = 256, CIN = 64;
+    using Stager = HaloStager<SRC_DIRECT, TH, NTHR>;
+    constexpr int BUF = Stager::HALO * LSTR;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int tiles = tiles_x * tiles_y;
+    const int pt = bid % tiles;
+    const int img = bid / tiles;
+    const int tx0 = (pt % tiles_x) * TW, ty0 = (pt / tiles_x) * TH;
+    const rsrc_t src = make_rsrc(in + (size_t)img * H * W * CIN, (unsigned)H * W * CIN * 4u);
+
+    Stager st;
+    st.init(tid, ty0, tx0, H, W, H, W, CIN);
+    st.load(src, 0);
+    st.store(smem, tid);
+    __syncthreads();
+
+    const int py = tid >> 5, px = tid & 31;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    constexpr int NCH = CIN / KC;
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        const float* sbuf = smem + (c & 1) * BUF + (py * HW_ + px) * LSTR;
+        const bool more = c + 1 < NCH;
+        if (more) st.load(src, (c + 1) * KC * 4);
+        const float* __restrict__ wc = wpk + c * (9 * 4 * 12);
+#pragma unroll 1
+        for (int ty = 0; ty < 3; ++ty) {
+#pragma unroll 1
+            for (int tx = 0; tx < 3; ++tx) {
+                const float* sp = sbuf + (ty * HW_ + tx) * LSTR;
+                const float* __restrict__ w = wc + (ty * 3 + tx) * 48;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *(const f32x4*)(sp + q * 4);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        acc0 = fmaf(v[s], w[q * 12 + s * 3 + 0], acc0);
+                        acc1 = fmaf(v[s], w[q * 12 + s * 3 + 1], acc1);
+                        acc2 = fmaf(v[s], w[q * 12 + s * 3 + 2], acc2);
+                    }
+                }
+            }
+        }
+        if (more) st.store(smem + ((c + 1) & 1) * BUF, tid);
+        __syncthreads();
+    }
+    const int y = ty0 + py, x = tx0 + px;
+    if (y < H && x < W) {
+        float* __restrict__ o = out + (size_t)img * 3 * H * W + (size_t)y * W + x;
+        o[0] = acc0 + bias[0];
+        o[(size_t)H * W] = acc1 + bias[1];
+        o[(size_t)2 * H * W] = acc2 + bias[2];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------------------------
+int launch_pack_conv3x3(const float* w, float* p, int cin, int cout, hipStream_t s) {
+    if (cin % KC || cout % 32) { set_error("pack_conv3x3: cin %% 16 or cout %% 32 != 0 (%d, %d)", cin, cout); return -1; }
+    const size_t total = (size_t)cin * cout * 9;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(256), 0, s, w, p, cin, cout);
+    return check_launch("pack_conv3x3");
+}
+
+int launch_pack_conv_first(const float* w0, const float* b0, const float* w1, const float* b1, float* p,
+                           float* bias_out, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv_first_kernel, dim3(8), dim3(256), 0, s, w0, b0, w1, b1, p, bias_out);
+    return check_launch("pack_conv_first");
+}
+
+int launch_pack_conv_last(const float* w, float* p, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv_last_kernel, dim3(7), dim3(256), 0, s, w, p);
+    return check_launch("pack_conv_last");
+}
+
+template <int MODE, int WM, int WN, int MT, int NT>
+static int launch_cfg(ConvArgs a, hipStream_t s) {
+    constexpr int TH = WM * MT, BN = WN * NT * 32;
+    if (a.cout % BN) { set_error("conv3x3: cout %d not a multiple of %d", a.cout, BN); return -1; }
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    const long long blocks = (long long)a.tiles_x * a.tiles_y * (a.cout / BN) * a.n;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv3x3: bad grid %lld", blocks); return -1; }
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<MODE, WM, WN, MT, NT>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, a);
+    return check_launch("conv3x3");
+}
+
+int launch_conv3x3(const ConvArgs& a, int src_mode, hipStream_t s) {
+    if (a.cin % KC || a.cin < KC) { set_error("conv3x3: cin %d not a multiple of 16", a.cin); return -1; }
+    if (a.H < 2 || a.W < 2 || a.n < 1) { set_error("conv3x3: H, W must be >= 2 (reflection pad), got %dx%d", a.H, a.W); return -1; }
+    if ((size_t)a.Hs * a.Ws * a.cin * 4 >= 0x7fffffffULL) {
+        set_error("conv3x3: per-image source tensor must stay below 2 GiB (32-bit buffer offsets)");
+        return -1;
+    }
+    switch (src_mode) {
+        case SRC_DIRECT:
+            if (a.Hs != a.H || a.Ws != a.W) { set_error("conv3x3: direct mode needs Hs==H, Ws==W"); return -1; }
+            return launch_cfg<SRC_DIRECT, 4, 1, 2, 2>(a, s);
+        case SRC_UP2X:
+            if (a.H != 2 * a.Hs || a.W != 2 * a.Ws) { set_error("conv3x3: up2x mode needs H==2Hs, W==2Ws"); return -1; }
+            return launch_cfg<SRC_UP2X, 4, 1, 2, 2>(a, s);
+        case SRC_POOL2:
+            if (a.H != (a.Hs + 1) / 2 || a.W != (a.Ws + 1) / 2) { set_error("conv3x3: pool mode needs H==ceil(Hs/2), W==ceil(Ws/2)"); return -1; }
+            return launch_cfg<SRC_POOL2, 4, 1, 2, 2>(a, s);
+    }
+    set_error("conv3x3: unknown src_mode %d", src_mode);
+    return -1;
+}
+
+int launch_conv_first(const float* img, float* out, const float* packed, const float* bias, int n, int H, int W,
+                      hipStream_t s) {
+    if (H < 2 || W < 2 || n < 1) { set_error("conv_first: H, W must be >= 2, got %dx%d", H, W); return -1; }
+    const int tx = (W + 31) / 32, ty = (H + 7) / 8;
+    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(tx * ty * n)), dim3(256), 0, s, img, out, packed, bias, H, W, tx, ty);
+    return check_launch("conv_first");
+}
+
+int launch_conv_last(const float* in, float* out, const float* packed, const float* bias, int n, int H, int W,
+                     hipStream_t s) {
+    if (H < 2 || W < 2 || n < 1) { set_error("conv_last: H, W must be >= 2, got %dx%d", H, W); return -1; }
+    const int tx = (W + 31) / 32, ty = (H + 7) / 8;
+    hipLaunchKernelGGL(conv_last_kernel, dim3((unsigned)(tx * ty * n)), dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
+    return check_launch("conv_last");
+}
+
+}  // namespace adain

@@ -1,0 +1,354 @@
+"""ctypes binding of ``libadain_hip.so`` (the C ABI declared in include/adain_hip.h).
+
+PyTorch is used only for device memory, streams and (elsewhere) ``torch.distributed``: every
+compute call below hands raw device pointers (``tensor.data_ptr()``) and the current HIP stream to a
+hand-written gfx950 kernel.  There is NO fallback: if the shared library is missing or the tensors
+are not on a GPU, these functions raise.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libadain_hip.so")
+
+SRC_DIRECT, SRC_UP2X, SRC_POOL2 = 0, 1, 2
+
+_c_int, _c_float, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+_PP = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/adain_hip.h one to one
+SIGNATURES = {
+    "adain_abi_version": (_c_int, []),
+    "adain_last_error": (ctypes.c_char_p, []),
+    "adain_encoder_packed_floats": (_c_size_t, []),
+    "adain_decoder_packed_floats": (_c_size_t, []),
+    "adain_encoder_pack": (_c_int, [_PP, _PP, _c_void_p, _c_void_p]),
+    "adain_decoder_pack": (_c_int, [_PP, _PP, _c_void_p, _c_void_p]),
+    "adain_encoded_size": (None, [_c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
+    "adain_encode_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "adain_encode": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_int, _c_int, _PP, _c_void_p]),
+    "adain_decode_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "adain_decode": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_int, _c_int, _PP, _c_void_p]),
+    "adain_mean_std_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
+    "adain_mean_std": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "adain_blend_alpha": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
+                                   _c_float, _c_float, _c_void_p, _c_void_p]),
+    "adain_blend_pmap": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
+                                  _c_void_p, _c_int, _c_void_p, _c_void_p]),
+    "adain_strength_map_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "adain_strength_map": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "adain_resize_bilinear": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "adain_resize_nearest": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "adain_mask_composite": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
+    "adain_quantize_u8": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "adain_nhwc_to_nchw": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
+    "adain_nchw_to_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
+    "adain_conv3x3_packed_floats": (_c_size_t, [_c_int, _c_int]),
+    "adain_conv3x3_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
+    "adain_conv3x3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 9 + [_c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class AdainHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the shared library once.  Raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise AdainHipError(
+                        f"{LIB_PATH} is missing: build it with `python applied-image-processing_amd/build.py` "
+                        "(there is no CPU / PyTorch fallback for the AdaIN path)"
+                    )
+                l = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    f = getattr(l, name)
+                    f.restype, f.argtypes = res, args
+                if l.adain_abi_version() != 1:
+                    raise AdainHipError("libadain_hip.so ABI version mismatch")
+                _lib = l
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise AdainHipError(f"{what} failed ({rc}): {lib().adain_last_error().decode()}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise AdainHipError(f"{name}: expected a GPU tensor (the AdaIN path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise AdainHipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return ctypes.cast(arr, _PP), arr
+
+
+# --- workspaces: one growing scratch buffer per (device, tag) --------------------------------------------
+_ws = {}
+
+
+def workspace(device, tag, nbytes):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _ws.pop(key, None)
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def free_workspaces():
+    _ws.clear()
+
+
+# --- weights ------------------------------------------------------------------------------------------------
+ENC_KEYS = [0, 2, 5, 9, 12, 16, 19, 22, 25, 29]
+DEC_KEYS = [1, 5, 8, 11, 14, 18, 21, 25, 28]
+
+
+def pack_encoder(state_dict, device):
+    """state_dict with reference keys ("0.weight", "2.weight", ... ) -> packed device buffer."""
+    ws = [_dev(state_dict[f"{k}.weight"].to(device=device, dtype=torch.float32), "weight") for k in ENC_KEYS]
+    bs = [_dev(state_dict[f"{k}.bias"].to(device=device, dtype=torch.float32), "bias") for k in ENC_KEYS]
+    packed = torch.zeros(lib().adain_encoder_packed_floats(), dtype=torch.float32, device=device)
+    wp, _k1 = _ptr_array(ws)
+    bp, _k2 = _ptr_array(bs)
+    with torch.cuda.device(device):
+        _check(lib().adain_encoder_pack(wp, bp, packed.data_ptr(), _stream()), "adain_encoder_pack")
+        torch.cuda.current_stream().synchronize()   # the source tensors may be freed after return
+    return packed
+
+
+def pack_decoder(state_dict, device):
+    ws = [_dev(state_dict[f"{k}.weight"].to(device=device, dtype=torch.float32), "weight") for k in DEC_KEYS]
+    bs = [_dev(state_dict[f"{k}.bias"].to(device=device, dtype=torch.float32), "bias") for k in DEC_KEYS]
+    packed = torch.zeros(lib().adain_decoder_packed_floats(), dtype=torch.float32, device=device)
+    wp, _k1 = _ptr_array(ws)
+    bp, _k2 = _ptr_array(bs)
+    with torch.cuda.device(device):
+        _check(lib().adain_decoder_pack(wp, bp, packed.data_ptr(), _stream()), "adain_decoder_pack")
+        torch.cuda.current_stream().synchronize()
+    return packed
+
+
+# --- encoder / decoder -----------------------------------------------------------------------------------
+def encoded_size(h, w):
+    hc, wc = ctypes.c_int(), ctypes.c_int()
+    lib().adain_encoded_size(h, w, ctypes.byref(hc), ctypes.byref(wc))
+    return hc.value, wc.value
+
+
+def _event_array(events):
+    if events is None:
+        return None, None
+    arr = (ctypes.c_void_p * len(events))(*[e.cuda_event for e in events])
+    return ctypes.cast(arr, _PP), arr
+
+
+def encode(image, packed, events=None):
+    """image NCHW [n,3,h,w] -> relu4_1 features NHWC [n,hc,wc,512]."""
+    image = _dev(image, "image")
+    if image.dim() != 4 or image.shape[1] != 3:
+        raise AdainHipError(f"encode: expected [n,3,h,w], got {tuple(image.shape)}")
+    n, _, h, w = image.shape
+    hc, wc = encoded_size(h, w)
+    feat = torch.empty((n, hc, wc, 512), dtype=torch.float32, device=image.device)
+    nbytes = lib().adain_encode_workspace_bytes(n, h, w)
+    ws = workspace(image.device, "conv", nbytes)
+    ev, _keep = _event_array(events)
+    with torch.cuda.device(image.device):
+        _check(lib().adain_encode(image.data_ptr(), feat.data_ptr(), packed.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, ev,
+                                  _stream()), "adain_encode")
+    return feat
+
+
+def decode(feat, packed, events=None):
+    """features NHWC [n,hc,wc,512] -> image NCHW [n,3,8hc,8wc]."""
+    feat = _dev(feat, "feat")
+    if feat.dim() != 4 or feat.shape[3] != 512:
+        raise AdainHipError(f"decode: expected NHWC [n,hc,wc,512], got {tuple(feat.shape)}")
+    n, hc, wc, _ = feat.shape
+    img = torch.empty((n, 3, 8 * hc, 8 * wc), dtype=torch.float32, device=feat.device)
+    nbytes = lib().adain_decode_workspace_bytes(n, hc, wc)
+    ws = workspace(feat.device, "conv", nbytes)
+    ev, _keep = _event_array(events)
+    with torch.cuda.device(feat.device):
+        _check(lib().adain_decode(feat.data_ptr(), img.data_ptr(), packed.data_ptr(), ws.data_ptr(), ws.numel(), n, hc, wc, ev,
+                                  _stream()), "adain_decode")
+    return img
+
+
+# --- statistics and blend ------------------------------------------------------------------------------
+def mean_std(feat, nhwc, eps=1e-5):
+    """feat NHWC [n,h,w,c] (nhwc=True) or NCHW [n,c,h,w] -> (mean [n,c], std [n,c])."""
+    feat = _dev(feat, "feat")
+    assert feat.dim() == 4
+    if nhwc:
+        n, h, w, c = feat.shape
+    else:
+        n, c, h, w = feat.shape
+    mean = torch.empty((n, c), dtype=torch.float32, device=feat.device)
+    std = torch.empty_like(mean)
+    nbytes = lib().adain_mean_std_workspace_bytes(int(nhwc), n, c, h * w)
+    ws = workspace(feat.device, "stats", nbytes)
+    with torch.cuda.device(feat.device):
+        _check(lib().adain_mean_std(feat.data_ptr(), int(nhwc), n, c, h * w, eps, mean.data_ptr(), std.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), _stream()), "adain_mean_std")
+    return mean, std
+
+
+def _blend_dims(x, nhwc):
+    if nhwc:
+        n, h, w, c = x.shape
+    else:
+        n, c, h, w = x.shape
+    return n, c, h * w
+
+
+def blend_alpha(x, nhwc, c_mean, c_std, s_mean, s_std, alpha):
+    """AdaIN(x) * alpha + x * (1 - alpha);  alpha = 1 gives plain adaptive_instance_normalization."""
+    x = _dev(x, "content_feat")
+    n, c, hw = _blend_dims(x, nhwc)
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _check(lib().adain_blend_alpha(x.data_ptr(), int(nhwc), n, c, hw, c_mean.data_ptr(), c_std.data_ptr(), s_mean.data_ptr(),
+                                       s_std.data_ptr(), s_mean.shape[0], float(alpha), float(1 - alpha), out.data_ptr(), _stream()),
+               "adain_blend_alpha")
+    return out
+
+
+def blend_pmap(x, nhwc, c_mean, c_std, s_mean, s_std, pmap):
+    """AdaIN(x) * (1 - P) + x * P with P [pn, hc, wc] (pn in {1, n})."""
+    x = _dev(x, "content_feat")
+    pmap = _dev(pmap, "pmap")
+    n, c, hw = _blend_dims(x, nhwc)
+    pn = pmap.numel() // hw
+    if pn * hw != pmap.numel():
+        raise AdainHipError("blend_pmap: strength map size does not match the feature map")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _check(lib().adain_blend_pmap(x.data_ptr(), int(nhwc), n, c, hw, c_mean.data_ptr(), c_std.data_ptr(), s_mean.data_ptr(),
+                                      s_std.data_ptr(), s_mean.shape[0], pmap.data_ptr(), pn, out.data_ptr(), _stream()),
+               "adain_blend_pmap")
+    return out
+
+
+def strength_map(depth, hc, wc, offset, prominence):
+    """depth [h0,w0] -> P [1,1,hc,wc]."""
+    depth = _dev(depth, "depth_map")
+    if depth.dim() != 2:
+        raise AdainHipError(f"strength_map: expected a 2-D depth map, got {tuple(depth.shape)}")
+    h0, w0 = depth.shape
+    p = torch.empty((1, 1, hc, wc), dtype=torch.float32, device=depth.device)
+    ws = workspace(depth.device, "pmap", lib().adain_strength_map_workspace_bytes(hc, wc))
+    with torch.cuda.device(depth.device):
+        _check(lib().adain_strength_map(depth.data_ptr(), h0, w0, hc, wc, float(offset), float(prominence), p.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), _stream()), "adain_strength_map")
+    return p
+
+
+# --- pixel kernels -----------------------------------------------------------------------------------------
+def _resize(fn, name, x, size):
+    x = _dev(x, name)
+    assert x.dim() == 4
+    n, c, hi, wi = x.shape
+    ho, wo = size
+    out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(fn(x.data_ptr(), out.data_ptr(), n * c, hi, wi, ho, wo, _stream()), name)
+    return out
+
+
+def resize_bilinear(x, size):
+    return _resize(lib().adain_resize_bilinear, "adain_resize_bilinear", x, size)
+
+
+def resize_nearest(x, size):
+    return _resize(lib().adain_resize_nearest, "adain_resize_nearest", x, size)
+
+
+def mask_composite(content, stylized, mask):
+    """content, stylized NCHW [n,c,h,w]; mask [mn,mc,h,w] float -> content*(1-m) + stylized*m."""
+    content, stylized, mask = _dev(content, "content"), _dev(stylized, "stylized"), _dev(mask, "mask")
+    n, c, h, w = content.shape
+    if stylized.shape != content.shape or mask.shape[-2:] != content.shape[-2:]:
+        raise AdainHipError("mask_composite: shape mismatch")
+    out = torch.empty_like(content)
+    with torch.cuda.device(content.device):
+        _check(lib().adain_mask_composite(content.data_ptr(), stylized.data_ptr(), mask.data_ptr(), mask.shape[1], mask.shape[0],
+                                          out.data_ptr(), n, c, h * w, _stream()), "adain_mask_composite")
+    return out
+
+
+def quantize_u8(img):
+    """NCHW float [n,c,h,w] -> NHWC uint8 [n,h,w,c] (x*255 + 0.5, clamp, truncate)."""
+    img = _dev(img, "image")
+    n, c, h, w = img.shape
+    out = torch.empty((n, h, w, c), dtype=torch.uint8, device=img.device)
+    with torch.cuda.device(img.device):
+        _check(lib().adain_quantize_u8(img.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "adain_quantize_u8")
+    return out
+
+
+def nhwc_to_nchw(x):
+    x = _dev(x, "x")
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().adain_nhwc_to_nchw(x.data_ptr(), out.data_ptr(), n, c, h * w, _stream()), "adain_nhwc_to_nchw")
+    return out
+
+
+def nchw_to_nhwc(x):
+    x = _dev(x, "x")
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().adain_nchw_to_nhwc(x.data_ptr(), out.data_ptr(), n, c, h * w, _stream()), "adain_nchw_to_nhwc")
+    return out
+
+
+# --- single conv layer (tests / profiling) -------------------------------------------------------------
+def conv3x3_pack(w_oihw):
+    w = _dev(w_oihw, "weight")
+    cout, cin = w.shape[:2]
+    packed = torch.empty(lib().adain_conv3x3_packed_floats(cin, cout), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _check(lib().adain_conv3x3_pack(w.data_ptr(), packed.data_ptr(), cin, cout, _stream()), "adain_conv3x3_pack")
+    return packed
+
+
+def conv3x3(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True):
+    x = _dev(x_nhwc, "x")
+    n, hs, ws_, cin = x.shape
+    if src_mode == SRC_UP2X:
+        h, w = 2 * hs, 2 * ws_
+    elif src_mode == SRC_POOL2:
+        h, w = (hs + 1) // 2, (ws_ + 1) // 2
+    else:
+        h, w = hs, ws_
+    out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().adain_conv3x3(x.data_ptr(), out.data_ptr(), packed_w.data_ptr(), bias.data_ptr(), n, h, w, hs, ws_, cin, cout,
+                                   src_mode, int(relu), _stream()), "adain_conv3x3")
+    return out

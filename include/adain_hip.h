@@ -1,0 +1,126 @@
+/* adain_hip.h — C ABI of the MI355X (gfx950) AdaIN style-transfer inference path.
+ *
+ * The reference (Ayushkuruvilla/Applied-Image-Processing) has no FFI: its hot path is plain Python
+ * over torch ops (Style_3DGS/AdaIN/{function,net,test}.py).  These entry points are what a binding
+ * for that path would call instead of torch; each cites the reference code it replaces.  The
+ * Python host side (the modules under applied-image-processing_amd/AdaIN/) binds them with ctypes and keeps the
+ * reference's function names, argument meaning and error behaviour.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless named *_host; fp32 everywhere;
+ *   - the caller allocates every buffer, including workspaces sized by the *_bytes queries;
+ *   - images are NCHW (the reference's tensor layout); activations between the encoder and the
+ *     decoder are NHWC ("channels last"): [n][h][w][c];
+ *   - `stream` is a hipStream_t (NULL = the default stream); every call only enqueues work;
+ *   - return value 0 = ok, negative = error (ADAIN_E*); adain_last_error() gives the text of the
+ *     calling thread's last error.  No exceptions cross the ABI.  No call allocates, frees or
+ *     synchronises, so every call may be captured into a hipGraph.
+ */
+#ifndef ADAIN_HIP_H
+#define ADAIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADAIN_ABI_VERSION 1
+#define ADAIN_OK 0
+#define ADAIN_EINVAL (-1)  /* bad argument / unsupported shape */
+#define ADAIN_ELAUNCH (-2) /* HIP reported a launch error */
+
+#define ADAIN_SRC_DIRECT 0 /* conv input = source tensor */
+#define ADAIN_SRC_UP2X 1   /* conv input = nearest 2x upsample of the source (net.py:10,23,30) */
+#define ADAIN_SRC_POOL2 2  /* conv input = MaxPool2d(2,2,ceil_mode=True) of the source (net.py:46,53,66) */
+
+typedef void* adain_stream_t; /* hipStream_t */
+
+int adain_abi_version(void);
+const char* adain_last_error(void);
+
+/* ---- weights: pack a reference state_dict once (net.vgg / net.decoder, net.py:6-92) ----------------
+ * w[i] / b[i] are the OIHW weight and bias tensors of the i-th conv in module order
+ * (encoder: state_dict keys 0,2,5,9,12,16,19,22,25,29 ; decoder: 1,5,8,11,14,18,21,25,28).
+ * `packed` receives MFMA-fragment-ordered weights + biases; its size is the *_floats query. */
+size_t adain_encoder_packed_floats(void);
+size_t adain_decoder_packed_floats(void);
+int adain_encoder_pack(const float* const* w_host_array_of_dev_ptrs, const float* const* b_host_array_of_dev_ptrs,
+                       float* packed, adain_stream_t stream);
+int adain_decoder_pack(const float* const* w_host_array_of_dev_ptrs, const float* const* b_host_array_of_dev_ptrs,
+                       float* packed, adain_stream_t stream);
+
+/* ---- encoder: vgg[:31](x), conv0 .. relu4_1 (net.py:38-69; test.py:57,63,76-77,185) -----------------
+ * image NCHW [n][3][h][w] -> feat NHWC [n][hc][wc][512], hc = ceil(ceil(ceil(h/2)/2)/2) (same for w).
+ * layer_events: optional host array of 11 hipEvent_t recorded before layer 0 and after each of the
+ * 10 conv launches (profiling only; NULL in production). */
+void adain_encoded_size(int h, int w, int* hc, int* wc);
+size_t adain_encode_workspace_bytes(int n, int h, int w);
+int adain_encode(const float* image_nchw, float* feat_nhwc, const float* packed, void* workspace,
+                 size_t workspace_bytes, int n, int h, int w, void* const* layer_events, adain_stream_t stream);
+
+/* ---- decoder: net.decoder(feat) (net.py:6-36; test.py:71,81) ----------------------------------------
+ * feat NHWC [n][hc][wc][512] -> image NCHW [n][3][8hc][8wc].  layer_events: 10 events (before + 9 convs). */
+size_t adain_decode_workspace_bytes(int n, int hc, int wc);
+int adain_decode(const float* feat_nhwc, float* image_nchw, const float* packed, void* workspace,
+                 size_t workspace_bytes, int n, int hc, int wc, void* const* layer_events, adain_stream_t stream);
+
+/* ---- calc_mean_std (function.py:4-12): per (n, c) mean and sqrt(unbiased var + eps) over h*w ---------
+ * nhwc != 0: feat is [n][hw][c]; nhwc == 0: feat is [n][c][hw].  mean/std: [n][c]. */
+size_t adain_mean_std_workspace_bytes(int nhwc, int n, int c, int hw);
+int adain_mean_std(const float* feat, int nhwc, int n, int c, int hw, float eps, float* mean, float* std_out,
+                   void* workspace, size_t workspace_bytes, adain_stream_t stream);
+
+/* ---- adaptive_instance_normalization + blend (function.py:15-23; test.py:69-70, 79-80) -----------------
+ * t = (x - c_mean)/c_std * s_std + s_mean ;
+ *   alpha form: out = t*alpha + x*one_minus_alpha          (style_transfer_simple; plain AdaIN = 1, 0)
+ *   pmap  form: out = t*(1 - P) + x*P, P [pmap_n][hw]      (style_transfer, depth-aware)
+ * style_n and pmap_n are 1 (broadcast over the batch) or n. */
+int adain_blend_alpha(const float* content_feat, int nhwc, int n, int c, int hw, const float* c_mean,
+                      const float* c_std, const float* s_mean, const float* s_std, int style_n, float alpha,
+                      float one_minus_alpha, float* out, adain_stream_t stream);
+int adain_blend_pmap(const float* content_feat, int nhwc, int n, int c, int hw, const float* c_mean,
+                     const float* c_std, const float* s_mean, const float* s_std, int style_n, const float* pmap,
+                     int pmap_n, float* out, adain_stream_t stream);
+
+/* ---- compute_stylization_strength_map (test.py:119-150) ------------------------------------------------
+ * depth [h0][w0] -> pmap [hc][wc]: bicubic resize, min-max normalise, minus mean, sigmoid(prominence*P),
+ * clamp(max = 1 - offset); an exactly constant resized map gives zeros (test.py:141-143). */
+size_t adain_strength_map_workspace_bytes(int hc, int wc);
+int adain_strength_map(const float* depth, int h0, int w0, int hc, int wc, float offset, float prominence,
+                       float* pmap, void* workspace, size_t workspace_bytes, adain_stream_t stream);
+
+/* ---- content-mask composite of adain_inference (test.py:222-236) ---------------------------------------
+ * resize_*: `planes` independent [hi][wi] planes -> [ho][wo]; bilinear = F.interpolate(mode="bilinear",
+ * align_corners=False), nearest = F.interpolate(mode="nearest").
+ * mask_composite: out = content*(1-m) + stylized*m on NCHW [n][c][hw]; mask [mask_n][mask_c][hw],
+ * mask_c in {1, c}, mask_n in {1, n}. */
+int adain_resize_bilinear(const float* in, float* out, int planes, int hi, int wi, int ho, int wo,
+                          adain_stream_t stream);
+int adain_resize_nearest(const float* in, float* out, int planes, int hi, int wi, int ho, int wo,
+                         adain_stream_t stream);
+int adain_mask_composite(const float* content, const float* stylized, const float* mask, int mask_c, int mask_n,
+                         float* out, int n, int c, int hw, adain_stream_t stream);
+
+/* ---- torchvision save_image quantiser (test.py:243-244): NCHW float -> NHWC u8, x*255+0.5 clamped ------ */
+int adain_quantize_u8(const float* image_nchw, uint8_t* out_nhwc, int n, int c, int h, int w,
+                      adain_stream_t stream);
+
+/* ---- layout changes at the boundary ([n][c][hw] <-> [n][hw][c]) ------------------------------------------ */
+int adain_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, adain_stream_t stream);
+int adain_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, adain_stream_t stream);
+
+/* ---- single layers (unit tests, profiling) ----------------------------------------------------------------
+ * conv3x3: ReflectionPad2d(1) + Conv2d(cin, cout, 3) [+ ReLU] on NHWC, with the pool / upsample of the
+ * producer fused into the input gather (src_mode).  (h, w) = output size; (hs, ws) = source size.
+ * cin % 16 == 0, cout % 64 == 0. */
+size_t adain_conv3x3_packed_floats(int cin, int cout);
+int adain_conv3x3_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
+int adain_conv3x3(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,
+                  int w, int hs, int ws, int cin, int cout, int src_mode, int relu, adain_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAIN_HIP_H */
