@@ -20,11 +20,14 @@ void set_error(const char* fmt, ...) {
 // 8 generic 3x3 convs; the ceil-mode max-pools in front of conv2_1, conv3_1, conv4_1 are fused into those
 // convs' gathers.  Decoder = net.decoder (net.py:6-36): 8 generic convs (the nearest-2x upsamples in front
 // of the 2nd, 6th and 8th are fused into their gathers) + the 64->3 "last" conv.
-struct Layer { int cin, cout, src; };
-static const Layer ENC[8] = {{64, 64, SRC_DIRECT},  {64, 128, SRC_POOL2},  {128, 128, SRC_DIRECT}, {128, 256, SRC_POOL2},
-                             {256, 256, SRC_DIRECT}, {256, 256, SRC_DIRECT}, {256, 256, SRC_DIRECT}, {256, 512, SRC_POOL2}};
-static const Layer DEC[8] = {{512, 256, SRC_DIRECT}, {256, 256, SRC_UP2X},   {256, 256, SRC_DIRECT}, {256, 256, SRC_DIRECT},
-                             {256, 128, SRC_DIRECT}, {128, 128, SRC_UP2X},   {128, 64, SRC_DIRECT},  {64, 64, SRC_UP2X}};
+// `pool` = the layer's output feeds a max-pool: the pool is fused into this layer's EPILOGUE (only the pooled
+// tensor is written), so the next conv reads it directly.  (The consumer-side form, SRC_POOL2, stays available
+// through adain_conv3x3.)
+struct Layer { int cin, cout, src, pool; };
+static const Layer ENC[8] = {{64, 64, SRC_DIRECT, 1},   {64, 128, SRC_DIRECT, 0},  {128, 128, SRC_DIRECT, 1}, {128, 256, SRC_DIRECT, 0},
+                             {256, 256, SRC_DIRECT, 0}, {256, 256, SRC_DIRECT, 0}, {256, 256, SRC_DIRECT, 1}, {256, 512, SRC_DIRECT, 0}};
+static const Layer DEC[8] = {{512, 256, SRC_DIRECT, 0}, {256, 256, SRC_UP2X, 0},   {256, 256, SRC_DIRECT, 0}, {256, 256, SRC_DIRECT, 0},
+                             {256, 128, SRC_DIRECT, 0}, {128, 128, SRC_UP2X, 0},   {128, 64, SRC_DIRECT, 0},  {64, 64, SRC_UP2X, 0}};
 
 static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
 constexpr size_t FIRST_W = 2 * 4 * 64 * 4, FIRST_B = 64, LAST_W = 4 * 9 * 4 * 4 * 3, LAST_B = 3;
@@ -123,9 +126,27 @@ void adain_encoded_size(int h, int w, int* hc, int* wc) {
     if (wc) *wc = w;
 }
 
+// Ping-pong activation buffers of the encoder: A takes conv1_1's output and then every second layer, B the
+// others; sizes are the maxima over the schedule (ceil-mode pooling makes odd sizes non-monotonic).
+static void enc_buf_sizes(int n, int h, int w, size_t* a_floats, size_t* b_floats) {
+    size_t mx[2] = {(size_t)n * h * w * 64, 0};
+    int cur = 0, ch = h, cw = w;
+    for (int i = 0; i < 7; ++i) {   // layer 7 writes the caller's feature buffer
+        const int oh = ENC[i].pool ? (ch + 1) / 2 : ch, ow = ENC[i].pool ? (cw + 1) / 2 : cw;
+        const size_t sz = (size_t)n * oh * ow * ENC[i].cout;
+        cur ^= 1;
+        if (sz > mx[cur]) mx[cur] = sz;
+        ch = oh; cw = ow;
+    }
+    *a_floats = align64(mx[0]);
+    *b_floats = align64(mx[1]);
+}
+static size_t enc_buf_a(int n, int h, int w) { size_t a, b; enc_buf_sizes(n, h, w, &a, &b); return a; }
+static size_t enc_buf_b(int n, int h, int w) { size_t a, b; enc_buf_sizes(n, h, w, &a, &b); return b; }
+
 size_t adain_encode_workspace_bytes(int n, int h, int w) {
     if (n < 1 || h < 1 || w < 1) return 0;
-    return 2 * align64((size_t)n * h * w * 64) * sizeof(float);
+    return (enc_buf_a(n, h, w) + enc_buf_b(n, h, w)) * sizeof(float);
 }
 
 int adain_encode(const float* image, float* feat, const float* packed, void* workspace, size_t ws_bytes, int n, int h,
@@ -141,7 +162,7 @@ int adain_encode(const float* image, float* feat, const float* packed, void* wor
     size_t wo[8], bo[8], fb;
     enc_offsets(wo, bo, &fb);
     float* bufA = (float*)workspace;
-    float* bufB = bufA + align64((size_t)n * h * w * 64);
+    float* bufB = bufA + enc_buf_a(n, h, w);
     record(ev, 0, s);
     RET_IF(launch_conv_first(image, bufA, packed, packed + fb, n, h, w, s));
     record(ev, 1, s);
@@ -155,13 +176,14 @@ int adain_encode(const float* image, float* feat, const float* packed, void* wor
         a.bias = packed + bo[i];
         a.n = n;
         a.Hs = ch; a.Ws = cw;
-        if (ENC[i].src == SRC_POOL2) { ch = (ch + 1) / 2; cw = (cw + 1) / 2; }
         a.H = ch; a.W = cw;
         a.cin = ENC[i].cin; a.cout = ENC[i].cout;
         a.relu = 1;
-        RET_IF(launch_conv3x3(a, ENC[i].src, s));
+        a.pool_out = ENC[i].pool;
+        RET_IF(launch_conv3x3(a, ENC[i].src, -1, s));
         record(ev, i + 2, s);
         cur = a.out;
+        if (ENC[i].pool) { ch = (ch + 1) / 2; cw = (cw + 1) / 2; }
     }
     return 0;
 }
@@ -197,7 +219,7 @@ int adain_decode(const float* feat, float* image, const float* packed, void* wor
         a.H = ch; a.W = cw;
         a.cin = DEC[i].cin; a.cout = DEC[i].cout;
         a.relu = 1;
-        RET_IF(launch_conv3x3(a, DEC[i].src, s));
+        RET_IF(launch_conv3x3(a, DEC[i].src, -1, s));
         record(ev, i + 1, s);
         cur = a.out;
     }
@@ -271,13 +293,18 @@ int adain_conv3x3_pack(const float* w, float* packed, int cin, int cout, adain_s
     return launch_pack_conv3x3(w, packed, cin, cout, (hipStream_t)stream);
 }
 
+static unsigned long long* g_conv_dbg = nullptr;
+/* not part of the public ABI: tools/clock_probe.py sets a device buffer for the diagnostic variant 10 */
+int adain_debug_set_conv_stamp_buffer(void* p) { g_conv_dbg = (unsigned long long*)p; return 0; }
+
 int adain_conv3x3(const float* in, float* out, const float* packed_w, const float* bias, int n, int h, int w, int hs, int ws,
-                  int cin, int cout, int src_mode, int relu, adain_stream_t stream) {
+                  int cin, int cout, int src_mode, int relu, int pool_out, int variant, adain_stream_t stream) {
     if (!in || !out || !packed_w || !bias) { set_error("conv3x3: null pointer"); return ADAIN_EINVAL; }
     ConvArgs a{};
+    a.dbg = (variant == 10) ? g_conv_dbg : nullptr;
     a.in = in; a.out = out; a.wpk = packed_w; a.bias = bias;
-    a.n = n; a.H = h; a.W = w; a.Hs = hs; a.Ws = ws; a.cin = cin; a.cout = cout; a.relu = relu;
-    return launch_conv3x3(a, src_mode, (hipStream_t)stream);
+    a.n = n; a.H = h; a.W = w; a.Hs = hs; a.Ws = ws; a.cin = cin; a.cout = cout; a.relu = relu; a.pool_out = pool_out ? 1 : 0;
+    return launch_conv3x3(a, src_mode, variant, (hipStream_t)stream);
 }
 
 }  // extern "C"

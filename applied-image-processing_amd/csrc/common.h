@@ -24,7 +24,9 @@ struct ConvArgs {
     int Hs, Ws;         // source spatial size
     int cin, cout;
     int relu;
+    int pool_out;       // 1: write only MaxPool2d(2,2,ceil_mode=True)(output), [n][ceil(H/2)][ceil(W/2)][cout]
     int tiles_x, tiles_y;
+    unsigned long long* dbg;   // diagnostic builds only (clock stamps); nullptr in production
 };
 
 // thread-local error text for adain_last_error()
@@ -35,7 +37,7 @@ int launch_pack_conv3x3(const float* w_oihw, float* packed, int cin, int cout, h
 int launch_pack_conv_first(const float* w0, const float* b0, const float* w1, const float* b1, float* packed,
                            float* bias_out, hipStream_t s);
 int launch_pack_conv_last(const float* w, float* packed, hipStream_t s);
-int launch_conv3x3(const ConvArgs& a, int src_mode, hipStream_t s);
+int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s);   // variant < 0: automatic
 int launch_conv_first(const float* img_nchw, float* out_nhwc, const float* packed, const float* bias, int n, int H,
                       int W, hipStream_t s);
 int launch_conv_last(const float* in_nhwc, float* out_nchw, const float* packed, const float* bias, int n, int H,

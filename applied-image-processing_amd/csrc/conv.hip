@@ -188,15 +188,17 @@ struct HaloStager {
 // chunk's halo travels HBM -> registers during the whole chunk and is written to the other LDS
 // buffer just before the single barrier per chunk.
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int WM, int WN, int MT, int NT>
+template <int MODE, int WM, int WN, int MT, int NT, int LDSPAD, int PF = 2, int EXPER = 0>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma_kernel(ConvArgs a) {
     constexpr int TH = WM * MT;
     constexpr int NTHR = WM * WN * 64;
     using Stager = HaloStager<MODE, TH, NTHR>;
     constexpr int BUF = Stager::HALO * LSTR;
     constexpr int NSTEP = 9 * (KC / 8);   // k-groups per chunk (18)
-    static_assert(NSTEP % 3 == 0, "ring slot bookkeeping assumes NSTEP % 3 == 0");
-    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+    constexpr int RING = PF + 1;          // weight-fragment register ring: PF k-groups in flight
+    static_assert(NSTEP % RING == 0, "ring slot bookkeeping assumes NSTEP % RING == 0");
+    // LDSPAD floats of unused LDS cap the number of co-resident blocks per CU (occupancy tuning knob)
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF + LDSPAD];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -215,6 +217,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma_kernel(ConvArgs a) 
 
     const rsrc_t src = make_rsrc(a.in + (size_t)img * a.Hs * a.Ws * a.cin, (unsigned)a.Hs * a.Ws * a.cin * 4u);
     const rsrc_t wsr = make_rsrc(a.wpk, (unsigned)a.cin * a.cout * 36u);
+    unsigned long long t0c = 0, t0r = 0, tentry = 0;
+    if constexpr (EXPER == 2) tentry = __builtin_amdgcn_s_memrealtime();   // diagnostic build only
 
     Stager st;
     st.init(tid, ty0, tx0, a.H, a.W, a.Hs, a.Ws, a.cin);
@@ -235,16 +239,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma_kernel(ConvArgs a) 
 
     const int a_base = ((wm * MT) * HW_ + li) * LSTR + lh * 4;
 
-    f32x4 bq[3][NT];
+    f32x4 bq[RING][NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        bq[0][n] = buf_load4(wsr, wvo, wso + n * tile_bytes);
-        bq[1][n] = buf_load4(wsr, wvo, wso + n * tile_bytes + 1024);
-    }
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bq[p][n] = buf_load4(wsr, wvo, wso + n * tile_bytes + p * 1024);
 
     st.load(src, 0);
     st.store(smem, tid);
     __syncthreads();
+    if constexpr (EXPER == 2) {   // shader clock = d(memtime) / d(memrealtime) * 100 MHz
+        t0c = __builtin_amdgcn_s_memtime();
+        t0r = __builtin_amdgcn_s_memrealtime();
+    }
 
     for (int c = 0; c < nchunks; ++c) {
         const float* sbuf = smem + (c & 1) * BUF + a_base;
@@ -264,14 +271,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma_kernel(ConvArgs a) 
             // record k+2 of the stream (runs harmlessly past the tile / buffer end on the last steps:
             // the descriptor's range check returns 0 there)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bq[(k + 2) % 3][n] = buf_load4(wsr, wvo, wso + n * tile_bytes + (k + 2) * 1024);
+            for (int n = 0; n < NT; ++n) bq[(k + PF) % RING][n] = buf_load4(wsr, wvo, wso + n * tile_bytes + (k + PF) * 1024);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[k & 1][m][s], bq[k % 3][n][s], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[k & 1][m][s], bq[k % RING][n][s], acc[m][n], 0, 0, 0);
             // keep the prefetch distance: without this fence hipcc sinks the loads of step k+2 down to
             // their first use and waits vmcnt(0) in front of every MFMA group
             __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);            // next step's A fragments (LDS) first
@@ -284,8 +291,56 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma_kernel(ConvArgs a) 
         __syncthreads();
     }
 
+    if constexpr (EXPER == 2) {
+        const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && a.dbg) {
+            a.dbg[6 * blockIdx.x] = t1c - t0c;
+            a.dbg[6 * blockIdx.x + 1] = t1r - t0r;
+            a.dbg[6 * blockIdx.x + 2] = tentry;
+            a.dbg[6 * blockIdx.x + 3] = t0r;
+            a.dbg[6 * blockIdx.x + 4] = t1r;
+        }
+        if (tid == 0 && a.dbg) a.dbg[6 * gridDim.x + blockIdx.x] =
+            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
     // epilogue: bias + ReLU, NHWC store.  C layout of the 32x32 tile: column (lane&31) = channel,
     // row = (r&3) + 8*(r>>2) + 4*(lane>>5) = pixel; each store instruction writes 2 x 128 B segments.
+    if constexpr (MT % 2 == 0) {
+        if (a.pool_out) {
+            // fused MaxPool2d(2,2,ceil_mode=True) of this layer's output (net.py:46,53,66): the 2x2 window of
+            // a pooled pixel is rows (m, m+1) x registers (r, r+1) of ONE lane, so the max is register-local and
+            // only the pooled tensor [ceil(H/2)][ceil(W/2)][cout] is written.  max commutes exactly with the
+            // monotone "+bias" and ReLU.  Windows clipped by the image edge use the valid elements only.
+            const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+#pragma unroll
+            for (int m = 0; m < MT; m += 2) {
+                const int y = ty0 + wm * MT + m;
+                if (y >= a.H) continue;
+                const bool row1 = y + 1 < a.H;
+                float* __restrict__ orow = a.out + ((size_t)img * Hp + (y >> 1)) * Wp * a.cout;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int co = ((ct * WN + wn) * NT + n) * 32 + li;
+                    const float b = a.bias[co];
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int x = tx0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const bool col1 = x + 1 < a.W;
+                        float v = acc[m][n][r];
+                        if (col1) v = fmaxf(v, acc[m][n][r + 1]);
+                        if (row1) {
+                            v = fmaxf(v, acc[m + 1][n][r]);
+                            if (col1) v = fmaxf(v, acc[m + 1][n][r + 1]);
+                        }
+                        v += b;
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        if (x < a.W) orow[(size_t)(x >> 1) * a.cout + co] = v;
+                    }
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int y = ty0 + wm * MT + m;
@@ -303,6 +358,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma_kernel(ConvArgs a) 
                 if (x < a.W) orow[(size_t)x * a.cout + co] = v;
             }
         }
+    }
+    if constexpr (EXPER == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0 && a.dbg) a.dbg[6 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -474,35 +533,66 @@ int launch_pack_conv_last(const float* w, float* p, hipStream_t s) {
     return check_launch("pack_conv_last");
 }
 
-template <int MODE, int WM, int WN, int MT, int NT>
+template <int MODE, int WM, int WN, int MT, int NT, int LDSPAD, int PF = 2, int EXPER = 0>
 static int launch_cfg(ConvArgs a, hipStream_t s) {
     constexpr int TH = WM * MT, BN = WN * NT * 32;
     if (a.cout % BN) { set_error("conv3x3: cout %d not a multiple of %d", a.cout, BN); return -1; }
+    if (a.pool_out && (MT % 2)) { set_error("conv3x3: this tile variant cannot fuse the output pool"); return -1; }
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
     const long long blocks = (long long)a.tiles_x * a.tiles_y * (a.cout / BN) * a.n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv3x3: bad grid %lld", blocks); return -1; }
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<MODE, WM, WN, MT, NT>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<MODE, WM, WN, MT, NT, LDSPAD, PF, EXPER>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, a);
     return check_launch("conv3x3");
 }
 
-int launch_conv3x3(const ConvArgs& a, int src_mode, hipStream_t s) {
+// Tile variants (block = WM x WN waves, wave tile = MT rows x 32 px by NT x 32 channels, PF = weight prefetch
+// depth in k-groups); measured with tools/tune_conv.py on the config-2 layer shapes:
+//   0: 8 rows x 64 ch,  4 waves of 2 rows x 64 ch, PF 5   (pool-out capable default)
+//   1: 8 rows x 128 ch, 8 waves (4x2) of 2 rows x 64 ch, PF 5   (+3 % on >= 128-channel layers with >= 512 blocks)
+//   2: 4 rows x 64 ch,  4 waves of 1 row x 64 ch, PF 5    (best without output pool; 2x the blocks for small maps)
+//   3: as 0 with PF 2 (round-1 baseline, kept for A/B runs)
+//   4: 4 rows x 64 ch,  2 waves of 2 rows x 64 ch, PF 2   (pool-out on small maps)
+//  10: DIAGNOSTIC build of 3 with clock / timeline stamps (tools/clock_probe.py); never used by the product path
+template <int MODE>
+static int launch_variant(const ConvArgs& a, int variant, hipStream_t s) {
+    switch (variant) {
+        case 0: return launch_cfg<MODE, 4, 1, 2, 2, 0, 5, 0>(a, s);
+        case 1: return launch_cfg<MODE, 4, 2, 2, 2, 0, 5, 0>(a, s);
+        case 2: return launch_cfg<MODE, 4, 1, 1, 2, 0, 5, 0>(a, s);
+        case 3: return launch_cfg<MODE, 4, 1, 2, 2, 0, 2, 0>(a, s);
+        case 4: return launch_cfg<MODE, 2, 1, 2, 2, 0, 2, 0>(a, s);
+        case 10: return launch_cfg<MODE, 4, 1, 2, 2, 0, 2, 2>(a, s);
+    }
+    set_error("conv3x3: unknown tile variant %d", variant);
+    return -1;
+}
+
+int conv3x3_auto_variant(const ConvArgs& a) {
+    const long long tiles8 = (long long)((a.W + 31) / 32) * ((a.H + 7) / 8) * a.n;
+    if (!a.pool_out) return 2;
+    if (a.cout % 128 == 0 && tiles8 * (a.cout / 128) >= 512) return 1;
+    return tiles8 * (a.cout / 64) >= 256 ? 0 : 4;
+}
+
+int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s) {
     if (a.cin % KC || a.cin < KC) { set_error("conv3x3: cin %d not a multiple of 16", a.cin); return -1; }
     if (a.H < 2 || a.W < 2 || a.n < 1) { set_error("conv3x3: H, W must be >= 2 (reflection pad), got %dx%d", a.H, a.W); return -1; }
     if ((size_t)a.Hs * a.Ws * a.cin * 4 >= 0x7fffffffULL) {
         set_error("conv3x3: per-image source tensor must stay below 2 GiB (32-bit buffer offsets)");
         return -1;
     }
+    if (variant < 0) variant = conv3x3_auto_variant(a);
     switch (src_mode) {
         case SRC_DIRECT:
             if (a.Hs != a.H || a.Ws != a.W) { set_error("conv3x3: direct mode needs Hs==H, Ws==W"); return -1; }
-            return launch_cfg<SRC_DIRECT, 4, 1, 2, 2>(a, s);
+            return launch_variant<SRC_DIRECT>(a, variant, s);
         case SRC_UP2X:
             if (a.H != 2 * a.Hs || a.W != 2 * a.Ws) { set_error("conv3x3: up2x mode needs H==2Hs, W==2Ws"); return -1; }
-            return launch_cfg<SRC_UP2X, 4, 1, 2, 2>(a, s);
+            return launch_variant<SRC_UP2X>(a, variant, s);
         case SRC_POOL2:
             if (a.H != (a.Hs + 1) / 2 || a.W != (a.Ws + 1) / 2) { set_error("conv3x3: pool mode needs H==ceil(Hs/2), W==ceil(Ws/2)"); return -1; }
-            return launch_cfg<SRC_POOL2, 4, 1, 2, 2>(a, s);
+            return launch_variant<SRC_POOL2>(a, variant, s);
     }
     set_error("conv3x3: unknown src_mode %d", src_mode);
     return -1;

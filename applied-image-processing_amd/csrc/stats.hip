@@ -64,22 +64,31 @@ __global__ __launch_bounds__(MS_THREADS) void mean_std_nhwc_partial(const float*
     }
 }
 
-__global__ void mean_std_finalize(const double* __restrict__ part, int c, int hw, int nblk, float eps,
-                                  float* __restrict__ mean, float* __restrict__ std_) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per channel: lanes stride over the partial blocks, then a fixed-order butterfly reduction
+__global__ __launch_bounds__(256) void mean_std_finalize(const double* __restrict__ part, int c, int hw, int nblk, float eps,
+                                                         float* __restrict__ mean, float* __restrict__ std_) {
+    const int lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int img = blockIdx.y;
     if (ch >= c) return;
     double s = 0, q = 0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
         const double* p = part + (((size_t)img * nblk + b) * c + ch) * 2;
         s += p[0];
         q += p[1];
     }
-    const double m = s / hw;
-    // unbiased variance (torch.var default, function.py:9); hw == 1 gives 0/0 = NaN like torch
-    const double var = (q - s * m) / (double)(hw - 1);
-    mean[(size_t)img * c + ch] = (float)m;
-    std_[(size_t)img * c + ch] = sqrtf((float)var + eps);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off, 64);
+        q += __shfl_xor(q, off, 64);
+    }
+    if (lane == 0) {
+        const double m = s / hw;
+        // unbiased variance (torch.var default, function.py:9); hw == 1 gives 0/0 = NaN like torch
+        const double var = (q - s * m) / (double)(hw - 1);
+        mean[(size_t)img * c + ch] = (float)m;
+        std_[(size_t)img * c + ch] = sqrtf((float)var + eps);
+    }
 }
 
 // ---- NCHW: feat [n][c][hw] ; one block per (n, c) plane -------------------------------------------------
@@ -140,7 +149,7 @@ int launch_mean_std(const float* feat, int nhwc, int n, int c, int hw, float eps
         const int nblk = nhwc_blocks(c, hw);
         if (ws_bytes < mean_std_workspace_bytes(1, n, c, hw) || !workspace) { set_error("mean_std: workspace too small"); return -1; }
         hipLaunchKernelGGL(mean_std_nhwc_partial, dim3(nblk, n), dim3(MS_THREADS), 0, s, feat, c, hw, nblk, (double*)workspace);
-        hipLaunchKernelGGL(mean_std_finalize, dim3((c + 255) / 256, n), dim3(256), 0, s, (const double*)workspace, c, hw, nblk, eps, mean, std_);
+        hipLaunchKernelGGL(mean_std_finalize, dim3((c + 3) / 4, n), dim3(256), 0, s, (const double*)workspace, c, hw, nblk, eps, mean, std_);
     } else {
         hipLaunchKernelGGL(mean_std_nchw_kernel, dim3((unsigned)((size_t)n * c)), dim3(MS_THREADS), 0, s, feat, hw, eps, mean, std_);
     }

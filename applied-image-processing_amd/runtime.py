@@ -48,7 +48,7 @@ SIGNATURES = {
     "adain_nchw_to_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_conv3x3_packed_floats": (_c_size_t, [_c_int, _c_int]),
     "adain_conv3x3_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
-    "adain_conv3x3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 9 + [_c_void_p]),
+    "adain_conv3x3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 11 + [_c_void_p]),
 }
 
 _lib = None
@@ -338,7 +338,7 @@ def conv3x3_pack(w_oihw):
     return packed
 
 
-def conv3x3(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True):
+def conv3x3(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, pool_out=False, variant=-1):
     x = _dev(x_nhwc, "x")
     n, hs, ws_, cin = x.shape
     if src_mode == SRC_UP2X:
@@ -347,8 +347,9 @@ def conv3x3(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True):
         h, w = (hs + 1) // 2, (ws_ + 1) // 2
     else:
         h, w = hs, ws_
-    out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+    oh, ow = ((h + 1) // 2, (w + 1) // 2) if pool_out else (h, w)
+    out = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _check(lib().adain_conv3x3(x.data_ptr(), out.data_ptr(), packed_w.data_ptr(), bias.data_ptr(), n, h, w, hs, ws_, cin, cout,
-                                   src_mode, int(relu), _stream()), "adain_conv3x3")
+                                   src_mode, int(relu), int(pool_out), int(variant), _stream()), "adain_conv3x3")
     return out

@@ -111,14 +111,17 @@ int adain_quantize_u8(const float* image_nchw, uint8_t* out_nhwc, int n, int c, 
 int adain_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, adain_stream_t stream);
 int adain_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, adain_stream_t stream);
 
-/* ---- single layers (unit tests, profiling) ----------------------------------------------------------------
+/* ---- single layers (unit tests, profiling, tuning) ------------------------------------------------------
  * conv3x3: ReflectionPad2d(1) + Conv2d(cin, cout, 3) [+ ReLU] on NHWC, with the pool / upsample of the
- * producer fused into the input gather (src_mode).  (h, w) = output size; (hs, ws) = source size.
- * cin % 16 == 0, cout % 64 == 0. */
+ * producer fused into the input gather (src_mode) and/or the max-pool behind this layer fused into the
+ * epilogue (pool_out != 0: out is [n][ceil(h/2)][ceil(w/2)][cout]).  (h, w) = conv output size before any
+ * output pool; (hs, ws) = source size.  cin % 16 == 0, cout % 64 == 0.  variant < 0 selects the tile shape
+ * automatically; 0..4 force one (csrc/conv.hip, launch_variant). */
 size_t adain_conv3x3_packed_floats(int cin, int cout);
 int adain_conv3x3_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
 int adain_conv3x3(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,
-                  int w, int hs, int ws, int cin, int cout, int src_mode, int relu, adain_stream_t stream);
+                  int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out, int variant,
+                  adain_stream_t stream);
 
 #ifdef __cplusplus
 }

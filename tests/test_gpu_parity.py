@@ -83,6 +83,26 @@ def test_conv3x3_vs_oracle(rt, mode, shape):
     close(out2.permute(0, 3, 1, 2), F.conv2d(F.pad(src, (1, 1, 1, 1), mode="reflect"), w, b))
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("shape", [(1, 64, 128, 19, 45), (2, 128, 128, 8, 33)])
+def test_conv3x3_tile_variants_and_fused_output_pool(rt, variant, shape):
+    n, cin, cout, h, w = shape
+    x = T(synth.uniform_sym(110 + cin, (n, cin, h, w), 1.0))
+    wt = T(synth.uniform_sym(210 + cout, (cout, cin, 3, 3), (6.0 / (9 * cin)) ** 0.5))
+    b = T(synth.uniform_sym(310 + cout, (cout,), 0.1))
+    ref = F.relu(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), wt, b))
+    xg = x.cuda().permute(0, 2, 3, 1).contiguous()
+    packed = rt.conv3x3_pack(wt.cuda())
+    out = rt.conv3x3(xg, packed, b.cuda(), cout, rt.SRC_DIRECT, relu=True, variant=variant)
+    close(out.permute(0, 3, 1, 2), ref)
+    if variant != 2:   # variant 2 (one row per wave) cannot pool in registers and must say so
+        outp = rt.conv3x3(xg, packed, b.cuda(), cout, rt.SRC_DIRECT, relu=True, pool_out=True, variant=variant)
+        close(outp.permute(0, 3, 1, 2), F.max_pool2d(ref, 2, 2, 0, ceil_mode=True))
+    else:
+        with pytest.raises(rt.AdainHipError):
+            rt.conv3x3(xg, packed, b.cuda(), cout, rt.SRC_DIRECT, relu=True, pool_out=True, variant=variant)
+
+
 def test_conv3x3_rejects_bad_shapes(rt):
     x = torch.zeros(1, 4, 4, 24, device="cuda")
     with pytest.raises(rt.AdainHipError):

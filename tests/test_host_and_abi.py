@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     hc, wc = ctypes.c_int(), ctypes.c_int()
     lib.adain_encoded_size(45, 67, ctypes.byref(hc), ctypes.byref(wc))
     assert (hc.value, wc.value) == (6, 9) == arch.encoded_size(45, 67)
-    assert lib.adain_encode_workspace_bytes(1, 1024, 1024) == 2 * 1024 * 1024 * 64 * 4
+    assert lib.adain_encode_workspace_bytes(1, 1024, 1024) == (64 + 16) * 1024 * 1024 * 4   # A: conv1_1 out, B: pooled conv1_2 out
 
 
 def test_no_cpu_fallback():
