@@ -63,3 +63,57 @@ class AdaINEngine:
 
     def to_u8(self, images):
         return rt.quantize_u8(images)
+
+
+def precompute_guides(engine, views, names, output_dir, masks=None, content_size=512, crop=False, alpha=0.5,
+                      depth_maps=None, depth_offset=0.5, depth_prominence=20, save_ext=".jpg", sub_batch=8):
+    """Batched counterpart of the guide-image loop of the reference's Style_3DGS/train.py:86-115: every view
+    is resized like ``adain_inference(content_size=...)`` does (test.py:190-200), stylised against the engine's
+    current style, composited with its mask (``gt_image_np > 0``, train.py:97) and written to
+    ``<output_dir>/<name><save_ext>`` — the same file naming, so the guide loss (train.py:208-221) reads it back
+    unchanged.  ``views`` are PIL images (or paths); same-sized views are processed ``sub_batch`` at a time.
+    Returns {name: Path}."""
+    from pathlib import Path
+
+    import numpy as np
+    from PIL import Image
+
+    from .AdaIN.test import save_image, test_transform
+
+    out_dir = Path(output_dir)
+    out_dir.mkdir(exist_ok=True, parents=True)
+    tf = test_transform(content_size, crop)
+    tensors = []
+    for v in views:
+        if isinstance(v, (str, Path)):
+            v = Image.open(str(v))
+        t = tf(v)
+        tensors.append(t[:3] if t.shape[0] == 4 else t)
+    paths = {}
+    i = 0
+    while i < len(tensors):
+        j = i + 1
+        while j < len(tensors) and j - i < sub_batch and tensors[j].shape == tensors[i].shape:
+            j += 1
+        content = torch.stack(tensors[i:j]).to(engine.device)
+        if depth_maps is not None:
+            out = engine.stylize_depth(content, [d.to(engine.device, torch.float32) for d in depth_maps[i:j]], depth_offset,
+                                       depth_prominence)
+        else:
+            out = engine.stylize(content, alpha)
+        for k in range(i, j):
+            img = out[k - i:k - i + 1]
+            if masks is not None and masks[k] is not None:
+                m = masks[k]
+                m = m if isinstance(m, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(m))
+                img = engine.composite(content[k - i:k - i + 1], img, m.float().unsqueeze(0))
+            p = out_dir / f"{names[k]}{save_ext}"
+            save_image(img, str(p))
+            paths[names[k]] = p
+        i = j
+    return paths
+
+
+def pooled_style_embedding(style_f):
+    """[1,512,h,w] relu4_1 features -> [1,512] (reference Style_3DGS/train.py:80-84: adaptive_avg_pool2d + view)."""
+    return style_f.float().mean(dim=(2, 3)).view(style_f.shape[0], style_f.shape[1])

@@ -1,0 +1,122 @@
+"""GPU tests at the full sizes of BASELINE.json configs 3-5 (config 2 is in test_gpu_parity.py): one unit per
+config against the CPU oracle (relative L2 <= 1e-4, PSNR >= 60 dB after the [0,1] clamp) plus size-independent
+properties for the batched paths (a batch equals its frames run one by one, bitwise; uint8 quantiser bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+import applied_image_processing_amd.synth as synth
+from oracle import adain_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.fixture(scope="module")
+def engine(weights):
+    from applied_image_processing_amd.engine import AdaINEngine
+
+    vgg_sd, dec_sd = weights
+    e = AdaINEngine(vgg_sd, dec_sd, "cuda:0")
+    e.set_style(T(synth.image(4, 1, 512, 512)).cuda())
+    return e
+
+
+def check(out, ref, what):
+    out = out.cpu()
+    rel = float((out - ref).norm() / ref.norm())
+    psnr = float(O.psnr(out.clamp(0, 1), ref.clamp(0, 1)).min())
+    print(f"{what}: relative L2 {rel:.3e}, PSNR {psnr:.1f} dB")
+    assert rel <= 1e-4 and psnr >= 60.0
+
+
+def test_config3_depth_aware_2048(engine, weights):
+    vgg_sd, dec_sd = weights
+    c = T(synth.image(5, 1, 2048, 2048))
+    s = T(synth.image(4, 1, 512, 512))
+    d = T(synth.smooth_depth(6, 2048, 2048))
+    out = engine.stylize_depth(c.cuda(), [d.cuda()], 0.15, 20)
+    assert tuple(out.shape) == (1, 3, 2048, 2048)
+    with torch.no_grad():
+        ref = O.style_transfer(vgg_sd, dec_sd, c, s, d, 1.0, 0.15, 20)
+    check(out, ref, "config3 2048^2 depth-aware")
+    # the strength map itself
+    from applied_image_processing_amd import runtime as rt
+
+    p = rt.strength_map(d.cuda(), 256, 256, 0.15, 20).cpu()
+    np.testing.assert_allclose(p.numpy(), O.compute_stylization_strength_map(d, (256, 256), 0.15, 20).numpy(), rtol=1e-4, atol=2e-5)
+    assert float(p.max()) <= 0.85 + 1e-7
+
+
+def test_config4_video_frames_1080p(engine, weights):
+    vgg_sd, dec_sd = weights
+    frames = T(np.concatenate([synth.image(7 + i, 1, 1080, 1920) for i in range(3)]))
+    s = T(synth.image(4, 1, 512, 512))
+    out = engine.stylize(frames.cuda(), 0.5)
+    assert tuple(out.shape) == (3, 3, 1080, 1920)            # 1080 = 8 * 135
+    with torch.no_grad():
+        ref0 = O.style_transfer_simple(vgg_sd, dec_sd, frames[:1], s, 0.5)
+    check(out[:1], ref0, "config4 1080p frame 0")
+    for i in range(3):                                        # batch == frame by frame, bitwise
+        assert torch.equal(engine.stylize(frames[i:i + 1].cuda(), 0.5)[0], out[i])
+    u8 = engine.to_u8(out).cpu()
+    assert tuple(u8.shape) == (3, 1080, 1920, 3) and u8.dtype == torch.uint8
+    assert torch.equal(u8, O.quantize_u8(out.cpu()))          # same float input -> bit-exact quantiser
+    # per-frame depth variant (reference video/utils.py:341-350 passes use_depth=True)
+    d = T(synth.smooth_depth(9, 1080, 1920))
+    outd = engine.stylize_depth(frames[:1].cuda(), [d.cuda()], 0.30, 20)
+    with torch.no_grad():
+        refd = O.style_transfer(vgg_sd, dec_sd, frames[:1], s, d, 1.0, 0.30, 20)
+    check(outd, refd, "config4 1080p frame 0 depth-aware")
+
+
+def test_config5_guide_views_1200x1600_masked(engine, weights, tmp_path):
+    vgg_sd, dec_sd = weights
+    s = T(synth.image(4, 1, 512, 512))
+    views = []
+    for i in range(2):
+        v = synth.image(1000 + i, 1, 1200, 1600)
+        bg = synth.uniform01(2000 + i, 1200 * 1600).reshape(1, 1, 1200, 1600) < 0.3    # ~30 % exact-zero background
+        views.append(np.where(bg, np.float32(0), v))
+    c = T(np.concatenate(views))
+    mask = (c > 0)                                                                  # [n,3,H,W] bool (train.py:97 per view)
+    out = engine.stylize(c.cuda(), 0.5)
+    comp = engine.composite(c.cuda(), out, mask.float().cuda())
+    assert tuple(comp.shape) == (2, 3, 1200, 1600)
+    with torch.no_grad():
+        ref = O.style_transfer_simple(vgg_sd, dec_sd, c[:1], s, 0.5)
+        refc = O.mask_composite(c[:1], ref, mask[0])
+    check(comp[:1], refc, "config5 1200x1600 view 0 masked composite")
+    assert torch.equal(comp[:, :, :][~mask].cpu(), c[~mask])                         # background pixels untouched
+    # the batched guide writer keeps the reference's file naming (train.py:99-114)
+    from PIL import Image
+    from applied_image_processing_amd.engine import pooled_style_embedding, precompute_guides
+
+    pil = [Image.fromarray((v[0].transpose(1, 2, 0) * 255).astype(np.uint8)) for v in views]
+    masks = [np.asarray(p.resize((682, 512))).transpose(2, 0, 1) > 0 for p in pil]
+    paths = precompute_guides(engine, pil, ["r_0", "r_1"], tmp_path / "stylized", masks=masks, content_size=512)
+    assert sorted(paths) == ["r_0", "r_1"] and all(p.exists() and p.suffix == ".jpg" for p in paths.values())
+    assert Image.open(paths["r_0"]).size == (682, 512)
+    emb = pooled_style_embedding(engine.features(s.cuda()).permute(0, 3, 1, 2))
+    with torch.no_grad():
+        want = torch.nn.functional.adaptive_avg_pool2d(O.encode(vgg_sd, s), (1, 1)).view(1, 512)
+    np.testing.assert_allclose(emb.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_run_depth_cli_offline(weights, tmp_path):
+    from PIL import Image
+    from applied_image_processing_amd.AdaIN import run_depth
+
+    torch.save(synth.to_torch(synth.vgg_state_dict(0, full=True)), tmp_path / "vgg.pth")
+    torch.save(synth.to_torch(synth.decoder_state_dict(0)), tmp_path / "dec.pth")
+    Image.fromarray((synth.image(71, 1, 80, 96)[0].transpose(1, 2, 0) * 255).astype(np.uint8)).save(tmp_path / "c.png")
+    Image.fromarray((synth.image(72, 1, 64, 64)[0].transpose(1, 2, 0) * 255).astype(np.uint8)).save(tmp_path / "s.png")
+    np.save(tmp_path / "d.npy", synth.smooth_depth(73, 80, 96))
+    p = run_depth.main(["--content", str(tmp_path / "c.png"), "--style", str(tmp_path / "s.png"), "--output", str(tmp_path / "o"),
+                        "--use_depth", "--depth_npy", str(tmp_path / "d.npy"), "--vgg", str(tmp_path / "vgg.pth"),
+                        "--decoder", str(tmp_path / "dec.pth")])
+    assert p == tmp_path / "o" / "stylized.jpg" and p.exists()
+    assert Image.open(p).size == (616, 512)      # content_size=512 default: 80x96 -> 512x614 -> decoder 8*ceil: 512x616
