@@ -277,6 +277,11 @@ int adain_quantize_u8(const float* in, uint8_t* out, int n, int c, int h, int w,
     if (!in || !out) { set_error("quantize_u8: null pointer"); return ADAIN_EINVAL; }
     return launch_quantize_u8(in, out, n, c, h, w, (hipStream_t)stream);
 }
+int adain_warp_blend_u8(const uint8_t* cur, const uint8_t* prev, const float* flow, uint8_t* out, int h, int w, int c, float alpha,
+                        float one_minus_alpha, adain_stream_t stream) {
+    if (!cur || !prev || !flow || !out) { set_error("warp_blend_u8: null pointer"); return ADAIN_EINVAL; }
+    return launch_warp_blend_u8(cur, prev, flow, out, h, w, c, alpha, one_minus_alpha, (hipStream_t)stream);
+}
 int adain_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, adain_stream_t stream) {
     if (!in || !out) { set_error("nhwc_to_nchw: null pointer"); return ADAIN_EINVAL; }
     return launch_nhwc_to_nchw(in, out, n, c, hw, (hipStream_t)stream);

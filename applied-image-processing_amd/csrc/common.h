@@ -59,6 +59,8 @@ int launch_resize_bilinear(const float* in, float* out, int planes, int hi, int 
 int launch_resize_nearest(const float* in, float* out, int planes, int hi, int wi, int ho, int wo, hipStream_t s);
 int launch_mask_composite(const float* content, const float* stylized, const float* mask, int mask_c, int mask_n,
                           float* out, int n, int c, int hw, hipStream_t s);
+int launch_warp_blend_u8(const uint8_t* cur, const uint8_t* prev, const float* flow, uint8_t* out, int h, int w, int c,
+                         float alpha, float one_minus_alpha, hipStream_t s);
 int launch_quantize_u8(const float* in_nchw, uint8_t* out_nhwc, int n, int c, int h, int w, hipStream_t s);
 int launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, hipStream_t s);

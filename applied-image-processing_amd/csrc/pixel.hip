@@ -223,6 +223,49 @@ int launch_quantize_u8(const float* in, uint8_t* out, int n, int c, int h, int w
     return check_launch("quantize_u8");
 }
 
+// ---- video post-pass (reference video/utils.py:89-105 warp_image, :223-229 blend_images) -------------------
+// out = u8( clip( (alpha * cur/255 + (1 - alpha) * warp(prev)/255) * 255, 0, 255 ) ), HWC uint8 frames;
+// warp(prev)(y, x) = bilinear sample of prev at (x + flow[0][y][x], y + flow[1][y][x]) with cv2.BORDER_REFLECT
+// (fedcba|abcdefgh|hgfedcb), rounded to uint8 like cv2.remap's uint8 output.  cv2 interpolates uint8 in 5-bit
+// fixed point; this kernel interpolates in fp32, so results can differ from OpenCV by 1 LSB (parity unpinned:
+// cv2 is not installed in the build image).
+__device__ __forceinline__ int reflect_border(int v, int n) {
+    const int p = 2 * n;      // BORDER_REFLECT has period 2n: ...cba|abc...xyz|zyx...
+    v %= p;
+    if (v < 0) v += p;
+    return v < n ? v : p - 1 - v;
+}
+
+__global__ __launch_bounds__(256) void warp_blend_u8_kernel(const uint8_t* __restrict__ cur, const uint8_t* __restrict__ prev,
+                                                            const float* __restrict__ flow, uint8_t* __restrict__ out, int h, int w,
+                                                            int c, float alpha, float one_minus_alpha) {
+    const int total = h * w;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int y = i / w, x = i - y * w;
+        const float mx = (float)x + flow[i], my = (float)y + flow[(size_t)total + i];
+        const float fx0 = floorf(mx), fy0 = floorf(my);
+        const float ax = mx - fx0, ay = my - fy0;
+        const int x0 = reflect_border((int)fx0, w), x1 = reflect_border((int)fx0 + 1, w);
+        const int y0 = reflect_border((int)fy0, h), y1 = reflect_border((int)fy0 + 1, h);
+        for (int ch = 0; ch < c; ++ch) {
+            const float p00 = prev[((size_t)y0 * w + x0) * c + ch], p01 = prev[((size_t)y0 * w + x1) * c + ch];
+            const float p10 = prev[((size_t)y1 * w + x0) * c + ch], p11 = prev[((size_t)y1 * w + x1) * c + ch];
+            const float top = p00 + ax * (p01 - p00), bot = p10 + ax * (p11 - p10);
+            const float wv = floorf(fminf(fmaxf(top + ay * (bot - top), 0.f), 255.f) + 0.5f);   // cv2 rounds to uint8
+            const float b = alpha * ((float)cur[(size_t)i * c + ch] / 255.0f) + one_minus_alpha * (wv / 255.0f);
+            out[(size_t)i * c + ch] = (uint8_t)fminf(fmaxf(b * 255.f, 0.f), 255.f);
+        }
+    }
+}
+
+int launch_warp_blend_u8(const uint8_t* cur, const uint8_t* prev, const float* flow, uint8_t* out, int h, int w, int c, float alpha,
+                         float one_minus_alpha, hipStream_t s) {
+    if (h < 1 || w < 1 || c < 1) { set_error("warp_blend_u8: bad shape"); return -1; }
+    hipLaunchKernelGGL(warp_blend_u8_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, s, cur, prev, flow, out, h, w, c, alpha,
+                       one_minus_alpha);
+    return check_launch("warp_blend_u8");
+}
+
 // ---- layout transposes through a 32x33 LDS tile: [n][R][C] -> [n][C][R] ------------------------------------
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
     __shared__ float tile[32][33];

@@ -44,6 +44,7 @@ SIGNATURES = {
     "adain_resize_nearest": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_mask_composite": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_quantize_u8": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "adain_warp_blend_u8": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p]),
     "adain_nhwc_to_nchw": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_nchw_to_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_conv3x3_packed_floats": (_c_size_t, [_c_int, _c_int]),
@@ -307,6 +308,19 @@ def quantize_u8(img):
     out = torch.empty((n, h, w, c), dtype=torch.uint8, device=img.device)
     with torch.cuda.device(img.device):
         _check(lib().adain_quantize_u8(img.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "adain_quantize_u8")
+    return out
+
+
+def warp_blend_u8(cur, prev, flow, alpha):
+    """Video post-pass: cur, prev uint8 [h,w,c]; flow float32 [2,h,w] -> blended uint8 [h,w,c]."""
+    cur, prev, flow = _dev(cur, "cur", torch.uint8), _dev(prev, "prev", torch.uint8), _dev(flow, "flow")
+    h, w, c = cur.shape
+    if prev.shape != cur.shape or tuple(flow.shape) != (2, h, w):
+        raise AdainHipError("warp_blend_u8: shape mismatch")
+    out = torch.empty_like(cur)
+    with torch.cuda.device(cur.device):
+        _check(lib().adain_warp_blend_u8(cur.data_ptr(), prev.data_ptr(), flow.data_ptr(), out.data_ptr(), h, w, c, float(alpha),
+                                         float(1 - alpha), _stream()), "adain_warp_blend_u8")
     return out
 
 

@@ -37,50 +37,31 @@ import applied_image_processing_amd.sharding as sh
 import applied_image_processing_amd.synth as synth
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)"
+WORKLOADS = {
+    2: "configs[1]: {h}x{w} AdaIN forward (style_transfer_simple), batch={b} per GPU, style {hs}x{ws} re-encoded every step, alpha=0.5",
+    3: "configs[2]: {h}x{w} depth-aware AdaIN (style_transfer, proximity-map blend), batch={b} per GPU, style {hs}x{ws} re-encoded every step",
+    4: "configs[3]: video frames {h}x{w}, {b} frames per GPU per step, one {hs}x{ws} style (statistics cached for the job), uint8 out",
+    5: "configs[4]: 3DGS guide views {h}x{w} with masks, {b} views per GPU per step, one {hs}x{ws} style, mask composite + uint8 out",
+}
 
 
-def conv3x3_layer_flops(h, w, hs, ws):
-    """Algorithmic flops (2 per MAC) of the generic 3x3 conv launches of one step, in launch order:
-    8 encoder convs for the content image, 8 for the style image, 8 decoder convs."""
-    def enc(hh, ww):
-        out = []
-        for L in arch.encoder_plan()[2:]:
-            if L["src"] == "pool":
-                hh, ww = (hh + 1) // 2, (ww + 1) // 2
-            out.append(2 * hh * ww * L["cin"] * L["cout"] * 9)
-        return out
-
-    def dec(hh, ww):
-        out = []
-        for L in arch.decoder_plan()[:-1]:
-            if L["src"] == "up":
-                hh, ww = 2 * hh, 2 * ww
-            out.append(2 * hh * ww * L["cin"] * L["cout"] * 9)
-        return out
-
-    hc, wc = arch.encoded_size(h, w)
-    return enc(h, w), enc(hs, ws), dec(hc, wc)
+def enc_conv3x3_flops(n, h, w):
+    """Algorithmic flops (2 per MAC) of the 8 generic 3x3 conv launches of one encoder pass, in launch order."""
+    out = []
+    for L in arch.encoder_plan()[2:]:
+        if L["src"] == "pool":
+            h, w = (h + 1) // 2, (w + 1) // 2
+        out.append(2 * n * h * w * L["cin"] * L["cout"] * 9)
+    return out
 
 
-class Step:
-    """style_transfer_simple on raw device buffers through the C ABI."""
-
-    def __init__(self, device, seed_offset=0, h=1024, w=1024, hs=512, ws=512, batch=1, alpha=0.5):
-        self.alpha = alpha
-        vgg_sd = synth.to_torch(synth.vgg_state_dict(0, full=False))
-        dec_sd = synth.to_torch(synth.decoder_state_dict(0))
-        self.enc = rt.pack_encoder(vgg_sd, device)
-        self.dec = rt.pack_decoder(dec_sd, device)
-        self.content = torch.from_numpy(synth.image(3 + 1000 * seed_offset, batch, h, w)).to(device)
-        self.style = torch.from_numpy(synth.image(4, 1, hs, ws)).to(device)
-
-    def run(self, ev_c=None, ev_s=None, ev_d=None):
-        cf = rt.encode(self.content, self.enc, ev_c)
-        sf = rt.encode(self.style, self.enc, ev_s)
-        c_mean, c_std = rt.mean_std(cf, True)
-        s_mean, s_std = rt.mean_std(sf, True)
-        g = rt.blend_alpha(cf, True, c_mean, c_std, s_mean, s_std, self.alpha)
-        return rt.decode(g, self.dec, ev_d)
+def dec_conv3x3_flops(n, hc, wc):
+    out = []
+    for L in arch.decoder_plan()[:-1]:
+        if L["src"] == "up":
+            hc, wc = 2 * hc, 2 * wc
+        out.append(2 * n * hc * wc * L["cin"] * L["cout"] * 9)
+    return out
 
 
 def make_events(n):
@@ -90,20 +71,104 @@ def make_events(n):
     return evs
 
 
-def measure_roofline(step, reps, h, w, hs, ws):
-    fl_c, fl_s, fl_d = conv3x3_layer_flops(h, w, hs, ws)
-    flops = fl_c + fl_s + fl_d
+class Step:
+    """One pass of the hot path on raw device buffers through the C ABI.  ``config``:
+    2: style_transfer_simple, 1024x1024 content + 512x512 style re-encoded every step (test.py:74-81)
+    3: style_transfer (depth-aware), 2048x2048 content + depth map + 512x512 style (test.py:52-71)
+    4: video frames 1080x1920, `batch` frames per step, ONE style for the job (statistics computed once, before the
+       timed region: a video has one style, video/utils.py:341), output quantised to uint8
+    5: 3DGS guide views 1200x1600 with masks, `batch` views per step, one style, mask composite + uint8 (train.py:86-115)
+    """
+
+    def __init__(self, device, config=2, seed_offset=0, size=None, style_size=512, batch=1, alpha=0.5):
+        self.config, self.alpha, self.batch = config, alpha, batch
+        self.h, self.w = {2: (1024, 1024), 3: (2048, 2048), 4: (1080, 1920), 5: (1200, 1600)}[config]
+        if size:
+            self.h = self.w = size
+        self.hs = self.ws = style_size
+        vgg_sd = synth.to_torch(synth.vgg_state_dict(0, full=False))
+        dec_sd = synth.to_torch(synth.decoder_state_dict(0))
+        self.enc = rt.pack_encoder(vgg_sd, device)
+        self.dec = rt.pack_decoder(dec_sd, device)
+        base = {2: 3, 3: 5, 4: 7, 5: 1000}[config] + 1000 * seed_offset
+        self.content = torch.cat([torch.from_numpy(synth.image(base + i, 1, self.h, self.w)) for i in range(batch)]).to(device)
+        self.style = torch.from_numpy(synth.image(4, 1, self.hs, self.ws)).to(device)
+        self.hc, self.wc = rt.encoded_size(self.h, self.w)
+        self.style_each_step = config in (2, 3)
+        if config == 3:
+            self.depth = [torch.from_numpy(synth.smooth_depth(6 + i, self.h, self.w)).to(device) for i in range(batch)]
+        if config == 5:
+            bg = torch.cat([torch.from_numpy(synth.uniform01(2000 + i, self.h * self.w).reshape(1, 1, self.h, self.w) < 0.3)
+                            for i in range(batch)]).to(device)
+            self.content = torch.where(bg, torch.zeros_like(self.content), self.content)
+            self.mask = (self.content > 0).float()
+        if not self.style_each_step:
+            sf = rt.encode(self.style, self.enc)
+            self.s_mean, self.s_std = rt.mean_std(sf, True)
+
+    def flops_per_step(self):
+        f = arch.conv_flops_encoder(self.h, self.w) * self.batch + arch.conv_flops_decoder(self.hc, self.wc) * self.batch
+        if self.style_each_step:
+            f += arch.conv_flops_encoder(self.hs, self.ws)
+        return f
+
+    def conv3x3_flops(self):
+        f = enc_conv3x3_flops(self.batch, self.h, self.w)
+        if self.style_each_step:
+            f += enc_conv3x3_flops(1, self.hs, self.ws)
+        return f + dec_conv3x3_flops(self.batch, self.hc, self.wc)
+
+    def run(self, timed=False):
+        ev = []
+        ev_c = make_events(11) if timed else None
+        cf = rt.encode(self.content, self.enc, ev_c)
+        if timed:
+            ev += [(ev_c[i + 1], ev_c[i + 2]) for i in range(8)]
+        if self.style_each_step:
+            ev_s = make_events(11) if timed else None
+            sf = rt.encode(self.style, self.enc, ev_s)
+            s_mean, s_std = rt.mean_std(sf, True)
+            if timed:
+                ev += [(ev_s[i + 1], ev_s[i + 2]) for i in range(8)]
+        else:
+            s_mean, s_std = self.s_mean, self.s_std
+        c_mean, c_std = rt.mean_std(cf, True)
+        if self.config == 3:
+            p = torch.cat([rt.strength_map(d, self.hc, self.wc, 0.15, 20) for d in self.depth])
+            g = rt.blend_pmap(cf, True, c_mean, c_std, s_mean, s_std, p)
+        else:
+            g = rt.blend_alpha(cf, True, c_mean, c_std, s_mean, s_std, self.alpha)
+        ev_d = make_events(10) if timed else None
+        out = rt.decode(g, self.dec, ev_d)
+        if timed:
+            ev += [(ev_d[i], ev_d[i + 1]) for i in range(8)]
+        if self.config == 5:
+            size = (self.h, self.w)
+            out = rt.mask_composite(self.content, rt.resize_bilinear(out, size), rt.resize_nearest(self.mask, size))
+        if self.config in (4, 5):
+            self.u8 = rt.quantize_u8(out)
+        return (out, ev) if timed else out
+
+
+def load_pmc_traffic(workload_key):
+    """HBM bytes per conv3x3 launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
+    tools/summarize_rocprof.py --traffic); None when no profile of this workload is committed."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return d.get(workload_key, {}).get("hbm_bytes_per_conv3x3_launch")
+    except Exception:
+        return None
+
+
+def measure_roofline(step, reps):
+    flops = step.conv3x3_flops()
     total_ms = 0.0
     per_layer = [0.0] * len(flops)
     for _ in range(reps):
-        ev_c, ev_s, ev_d = make_events(11), make_events(11), make_events(10)
-        step.run(ev_c, ev_s, ev_d)
+        _, ev = step.run(timed=True)
         torch.cuda.synchronize()
-        # encode: events 1..9 bracket the 8 generic convs; decode: events 0..8
-        d = [ev_c[i + 1].elapsed_time(ev_c[i + 2]) for i in range(8)]
-        d += [ev_s[i + 1].elapsed_time(ev_s[i + 2]) for i in range(8)]
-        d += [ev_d[i].elapsed_time(ev_d[i + 1]) for i in range(8)]
-        per_layer = [a + b for a, b in zip(per_layer, d)]
+        d = [a.elapsed_time(b) for a, b in ev]
+        per_layer = [x + y for x, y in zip(per_layer, d)]
         total_ms += sum(d)
     launches = len(flops) * reps
     avg_ms = total_ms / launches
@@ -111,8 +176,9 @@ def measure_roofline(step, reps, h, w, hs, ws):
     layers = [{"gflop": f / 1e9, "ms": t / reps, "tflops": f / (t / reps * 1e-3) / 1e12} for f, t in zip(flops, per_layer)]
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-        "kernel": "conv3x3_mfma_kernel (24 launches/step)", "avg_launch_ms": round(avg_ms, 4),
+        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+        "traffic": load_pmc_traffic(f"config{step.config}_batch{step.batch}"),
+        "kernel": f"conv3x3_mfma_kernel ({len(flops)} launches/step)", "avg_launch_ms": round(avg_ms, 4),
         "flop_per_launch_avg": sum(flops) / len(flops),
     }, layers
 
@@ -157,7 +223,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=1024, help="content H = W")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[] index + 1 (default 2 = configs[1])")
+    ap.add_argument("--size", type=int, default=0, help="override content H = W")
     ap.add_argument("--style-size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -175,16 +242,17 @@ def main():
         raise SystemExit("bench.py needs a GPU (the AdaIN path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ      # torch.distributed.run sets RANK even for one process
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    h = w = args.size
-    hs = ws = args.style_size
-    step = Step(device, seed_offset=rank, h=h, w=w, hs=hs, ws=ws, batch=args.batch)
+    step = Step(device, config=args.config, seed_offset=rank, size=args.size, style_size=args.style_size, batch=args.batch)
+    h, w, hs, ws = step.h, step.w, step.hs, step.ws
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -196,7 +264,7 @@ def main():
         out = step.run()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -204,7 +272,7 @@ def main():
     # final gather of the finished uint8 frames to rank 0 (outside the timed region)
     gather_ms = None
     u8 = rt.quantize_u8(out)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         torch.cuda.synchronize()
         g0 = time.perf_counter()
         allf = sh.gather_frames(u8, world * args.batch, dst=0)
@@ -217,23 +285,21 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * h * w / 1e6 / (dt / args.steps)
-        roof, layers = measure_roofline(step, 3, h, w, hs, ws) if args.batch == 1 else (None, None)
+        roof, layers = measure_roofline(step, 3)
         result = {
             "metric": "stylized Mpixels/sec, AdaIN forward (encode content + encode style + AdaIN + decode)",
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {h}x{w} AdaIN forward, batch={args.batch} per GPU, fp32, style {hs}x{ws} "
-                                   "re-encoded every step, alpha=0.5, seeded synthetic weights (reference architecture)",
+            "config": {"workload": WORKLOADS[args.config].format(h=h, w=w, hs=hs, ws=ws, b=args.batch)
+                                   + ", fp32, seeded synthetic weights (reference architecture)",
                        "parallelism": f"frame sharding x{world}, no data-path collective"},
             "roofline": roof,
         }
-        flop_step = (arch.conv_flops_encoder(h, w) + arch.conv_flops_encoder(hs, ws)
-                     + arch.conv_flops_decoder(*arch.encoded_size(h, w))) * args.batch
-        result["step_tflops"] = round(flop_step / (dt / args.steps) / 1e12 * world, 2)
+        result["step_tflops"] = round(step.flops_per_step() / (dt / args.steps) / 1e12 * world, 2)
         if gather_ms is not None:
             result["final_gather_ms"] = round(gather_ms, 3)
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and args.config == 2 and args.batch == 1:
             cb, psnr, rel = cpu_baseline(h, w, hs, ws, out)
             result["cpu_baseline"] = cb
             result["psnr_db_vs_cpu"] = round(psnr, 2)
@@ -242,7 +308,7 @@ def main():
             for i, L in enumerate(layers):
                 print(f"layer {i:2d}: {L['gflop']:8.2f} GF  {L['ms']:8.4f} ms  {L['tflops']:7.2f} TF/s", file=sys.stderr)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -148,3 +148,29 @@ def psnr(a, b):
     """Style_3DGS/utils/image_utils.py:17-19 — 20*log10(1/sqrt(mse)) per image on [0,1] data."""
     mse = ((a - b) ** 2).reshape(a.shape[0], -1).mean(1)
     return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
+def warp_blend_u8(cur, prev, flow, alpha):
+    """Reference video/utils.py:89-105 (warp_image: remap INTER_LINEAR, BORDER_REFLECT) + :223-229
+    (blend_images) on uint8 HWC numpy frames; flow [2,H,W].  numpy restatement with fp32 bilinear weights;
+    PARITY UNPINNED against OpenCV (cv2 absent): cv2.remap interpolates uint8 in 5-bit fixed point."""
+    import numpy as np
+
+    h, w, c = cur.shape
+    x, y = np.meshgrid(np.arange(w), np.arange(h))
+    mx = (x + flow[0]).astype(np.float32)
+    my = (y + flow[1]).astype(np.float32)
+    x0f, y0f = np.floor(mx), np.floor(my)
+    ax, ay = (mx - x0f)[..., None], (my - y0f)[..., None]
+
+    def refl(v, n):
+        v = np.mod(v.astype(np.int64), 2 * n)          # BORDER_REFLECT: fedcba|abcdefgh|hgfedcb, period 2n
+        return np.where(v < n, v, 2 * n - 1 - v)
+
+    x0, x1, y0, y1 = refl(x0f, w), refl(x0f + 1, w), refl(y0f, h), refl(y0f + 1, h)
+    p = prev.astype(np.float32)
+    top = p[y0, x0] + ax * (p[y0, x1] - p[y0, x0])
+    bot = p[y1, x0] + ax * (p[y1, x1] - p[y1, x0])
+    warped = np.floor(np.clip(top + ay * (bot - top), 0, 255) + np.float32(0.5)).astype(np.float32)
+    blended = np.float32(alpha) * (cur.astype(np.float32) / np.float32(255.0)) + np.float32(1 - alpha) * (warped / np.float32(255.0))
+    return np.clip(blended * np.float32(255), 0, 255).astype(np.uint8)

@@ -207,6 +207,21 @@ def test_pixel_kernels_vs_oracle(rt):
     assert torch.equal(rt.nhwc_to_nchw(rt.nchw_to_nhwc(f.cuda())).cpu(), f)
 
 
+def test_video_warp_blend_vs_oracle(rt):
+    h, w = 45, 61
+    cur = (synth.image(81, 1, h, w)[0].transpose(1, 2, 0) * 255).astype(np.uint8)
+    prev = (synth.image(82, 1, h, w)[0].transpose(1, 2, 0) * 255).astype(np.uint8)
+    flow = synth.uniform_sym(83, (2, h, w), 6.0)           # up to 6 px, leaves the frame near the borders
+    out = rt.warp_blend_u8(T(cur).cuda(), T(prev).cuda(), T(flow).cuda(), 0.7).cpu().numpy()
+    ref = O.warp_blend_u8(cur, prev, flow, 0.7)
+    diff = np.abs(out.astype(int) - ref.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02    # fp32 contraction differences only
+    # zero flow, alpha = 1 reproduces the current frame exactly; alpha = 0 the previous one
+    z = torch.zeros(2, h, w).cuda()
+    assert np.array_equal(rt.warp_blend_u8(T(cur).cuda(), T(prev).cuda(), z, 1.0).cpu().numpy(), cur)
+    assert np.abs(rt.warp_blend_u8(T(cur).cuda(), T(prev).cuda(), z, 0.0).cpu().numpy().astype(int) - prev.astype(int)).max() <= 1
+
+
 def test_mean_std_shapes_and_precision(rt):
     from applied_image_processing_amd.AdaIN import function as fn
 
