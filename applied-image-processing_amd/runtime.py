@@ -103,12 +103,13 @@ def _ptr_array(tensors):
     return ctypes.cast(arr, _PP), arr
 
 
-# --- workspaces: one growing scratch buffer per (device, tag) --------------------------------------------
+# --- workspaces: one growing scratch buffer per (device, stream, tag) -----------------------------------------
+# (keyed by stream so that independent frames can be in flight on different HIP streams)
 _ws = {}
 
 
 def workspace(device, tag, nbytes):
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream, tag)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None

@@ -112,6 +112,32 @@ class Step:
             f += arch.conv_flops_encoder(self.hs, self.ws)
         return f
 
+    def conv3x3_algorithmic_bytes(self):
+        """input + output + weights of every generic 3x3 conv launch of a step (what a launch must move at least)."""
+        def enc(n, h, w):
+            out = []
+            for L in arch.encoder_plan()[2:]:
+                if L["src"] == "pool":
+                    h, w = (h + 1) // 2, (w + 1) // 2
+                pooled = L["idx"] in (5, 12, 25)       # conv1_2, conv2_2, conv3_4 write only the pooled tensor
+                oh, ow = ((h + 1) // 2, (w + 1) // 2) if pooled else (h, w)
+                out.append(4 * (n * h * w * L["cin"] + n * oh * ow * L["cout"] + 9 * L["cin"] * L["cout"]))
+            return out
+
+        def dec(n, h, w):
+            out = []
+            for L in arch.decoder_plan()[:-1]:
+                ih, iw = h, w
+                if L["src"] == "up":
+                    h, w = 2 * h, 2 * w
+                out.append(4 * (n * ih * iw * L["cin"] + n * h * w * L["cout"] + 9 * L["cin"] * L["cout"]))
+            return out
+
+        b = enc(self.batch, self.h, self.w)
+        if self.style_each_step:
+            b += enc(1, self.hs, self.ws)
+        return b + dec(self.batch, self.hc, self.wc)
+
     def conv3x3_flops(self):
         f = enc_conv3x3_flops(self.batch, self.h, self.w)
         if self.style_each_step:
@@ -180,6 +206,7 @@ def measure_roofline(step, reps):
         "traffic": load_pmc_traffic(f"config{step.config}_batch{step.batch}"),
         "kernel": f"conv3x3_mfma_kernel ({len(flops)} launches/step)", "avg_launch_ms": round(avg_ms, 4),
         "flop_per_launch_avg": sum(flops) / len(flops),
+        "algorithmic_bytes_per_launch_avg": sum(step.conv3x3_algorithmic_bytes()) / len(flops),
     }, layers
 
 

@@ -53,5 +53,36 @@ def main(d):
                 print(f"| `{k}` | {c} | {a[0]} | {a[1] / a[0]:.4g} | {a[1]:.6g} |")
 
 
+def traffic(fetch_dir, write_dir, key, out_json):
+    """HBM bytes per conv3x3 launch = 2 * FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads,
+    MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KB per dispatch, from two separate --pmc passes."""
+    import json
+
+    def total(d, counter):
+        n, v = 0, 0.0
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "conv3x3_mfma_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    n += 1
+                    v += float(r["Counter_Value"])
+        return n, v
+
+    nf, f = total(fetch_dir, "FETCH_SIZE")
+    nw, w = total(write_dir, "WRITE_SIZE")
+    per_launch = (2.0 * f / nf + w / nw) * 1024.0
+    try:
+        d = json.load(open(out_json))
+    except Exception:
+        d = {}
+    d[key] = {"hbm_bytes_per_conv3x3_launch": round(per_launch), "fetch_kb_per_launch_raw": round(f / nf, 1),
+              "write_kb_per_launch": round(w / nw, 1), "dispatches": nf,
+              "note": "2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, averaged over every conv3x3_mfma_kernel dispatch of bench.py"}
+    json.dump(d, open(out_json, "w"), indent=1, sort_keys=True)
+    print(json.dumps(d[key]))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if sys.argv[1] == "--traffic":
+        traffic(*sys.argv[2:6])
+    else:
+        main(sys.argv[1])
