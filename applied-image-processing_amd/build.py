@@ -12,7 +12,7 @@ CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libadain_hip.so")
 SOURCES = ["conv.hip", "stats.hip", "pixel.hip", "api.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc():

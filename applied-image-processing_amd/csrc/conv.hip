@@ -21,6 +21,8 @@
 //     the group, k-step s uses element s), identically for A and B, so each b128 feeds 4 MFMAs.
 //   fp32 MFMA runs at the fp32 vector rate (64 cycles per 32x32x2), so HBM, L2 and LDS traffic are
 //   far below their limits; the kernel is bound by MFMA issue.
+#include <utility>
+
 #include "common.h"
 
 namespace adain {
@@ -366,6 +368,264 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma_kernel(ConvArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Persistent form of the same implicit GEMM.
+//
+// Why: in the one-tile-per-block kernel every resident block of a launch starts and ends at the same moment
+// (equal work), so once per "round" all CUs run their epilogues at once: a chip-wide burst of output stores
+// (tens of MB) during which no MFMA issues, then the block exit / dispatch / prologue latency.  A timeline probe
+// (tools/clock_probe.py) shows main loops at ~99 % MFMA occupancy but 9-40 us of store drain + 2 us of prologue
+// per 250 us round.  Here a block is resident for the whole launch and walks tiles t = b, b+G, b+2G, ...:
+//   * the finished tile's accumulators STAY in registers while the next tile accumulates into a second set, and
+//     are written out as a trickle (4 dwords per lane per k-group) during the next tile's first 16-channel chunk:
+//     no store burst, nothing waits for the stores;
+//   * the next tile's first halo chunk and its weight fragments are prefetched during the current tile's last
+//     chunk: no prologue bubble; the weight stream simply continues into the next tile's stream.
+// ---------------------------------------------------------------------------------------------
+struct TileId { int tx0, ty0, ct, img; };
+
+// Reads one accumulator element where it lives (the AGPR half of the register file).  Without this hipcc copies
+// the whole previous-tile accumulator (64 registers) into VGPRs before the trickle starts, which costs a wave of
+// occupancy; the "a" constraint keeps the value in its accumulator register until this point.
+__device__ __forceinline__ float acc_read(float in_acc) {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(in_acc));
+    return v;
+}
+
+__device__ __forceinline__ void buf_store1(rsrc_t r, float v, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+// Output addressing of one tile for the trickle epilogue: a buffer descriptor over the image's output tensor, one
+// per-lane byte offset (VGPR) and scalar offsets per element, so a store costs no vector address arithmetic.
+// A lane whose pixel falls outside the image gets an out-of-range offset: the descriptor's range check drops it.
+struct OutAddr {
+    rsrc_t rs;
+    int lane_off;   // bytes: (4*lh pixels) * cout + channel lane
+    int xlim;       // pixels of this lane's half still inside the row: W - tx0 - 4*lh
+};
+
+template <int MT, int NT, int WN, int STEP>
+__device__ __forceinline__ void trickle_store(const ConvArgs& a, const f32x16 (&acc)[MT][NT], const float (&bias)[NT],
+                                              const TileId& t, const OutAddr& o, int wm) {
+    // step STEP writes elements [4*STEP, 4*STEP+4): one (m, n) tile, registers r = 4q .. 4q+3 (4 consecutive pixels)
+    constexpr int E = STEP * 4;
+    if constexpr (E < MT * NT * 16) {
+        constexpr int m = E / (NT * 16), n = (E / 16) % NT, q = (E % 16) / 4;
+        const int y = t.ty0 + wm * MT + m;
+        if (y < a.H) {
+            const int row = ((y * a.W + t.tx0 + 8 * q) * a.cout + n * 32) * 4;   // scalar byte offset
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = acc_read(acc[m][n][4 * q + j]) + bias[n];
+                if (a.relu) v = fmaxf(v, 0.f);
+                buf_store1(o.rs, v, (8 * q + j < o.xlim) ? o.lane_off : 0x7fffffff, row + j * a.cout * 4);
+            }
+        }
+    }
+}
+
+template <int MT, int NT, int WN, int STEP>
+__device__ __forceinline__ void trickle_store_pooled(const ConvArgs& a, const f32x16 (&acc)[MT][NT], const float (&bias)[NT],
+                                                     const TileId& t, const OutAddr& o, int wm) {
+    // fused 2x2 ceil-mode max-pool of the output: step STEP writes pooled outputs [2*STEP, 2*STEP+2);
+    // o.lane_off here is (2*lh pooled pixels) * cout + channel lane, o.xlim as above (unpooled pixels)
+    constexpr int O = STEP * 2;
+    if constexpr (MT % 2 == 0 && O < (MT / 2) * NT * 8) {
+        constexpr int mp = O / (NT * 8), n = (O / 8) % NT, r0 = (O % 8) * 2;
+        constexpr int m = mp * 2;
+        const int Wp = (a.W + 1) >> 1;
+        const int y = t.ty0 + wm * MT + m;
+        if (y < a.H) {
+            const bool row1 = y + 1 < a.H;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                constexpr int dummy = 0; (void)dummy;
+                const int r = r0 + 2 * j;                       // even register: pixel x = tx0 + xr + 4*lh
+                const int xr = (r & 3) + 8 * (r >> 2);
+                const bool col1 = xr + 1 < o.xlim;
+                float v = acc_read(acc[m][n][r]);
+                v = col1 ? fmaxf(v, acc_read(acc[m][n][r + 1])) : v;
+                if (row1) {
+                    v = fmaxf(v, acc_read(acc[m + 1][n][r]));
+                    v = col1 ? fmaxf(v, acc_read(acc[m + 1][n][r + 1])) : v;
+                }
+                v += bias[n];
+                if (a.relu) v = fmaxf(v, 0.f);
+                const int soff = ((((y >> 1) * Wp + ((t.tx0 + xr) >> 1)) * a.cout) + n * 32) * 4;
+                buf_store1(o.rs, v, (xr < o.xlim) ? o.lane_off : 0x7fffffff, soff);
+            }
+        }
+    }
+}
+
+template <int MODE, int WM, int WN, int MT, int NT, int PF>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_persist_kernel(ConvArgs a) {
+    constexpr int TH = WM * MT;
+    constexpr int NTHR = WM * WN * 64;
+    using Stager = HaloStager<MODE, TH, NTHR>;
+    constexpr int BUF = Stager::HALO * LSTR;
+    constexpr int NSTEP = 9 * (KC / 8);
+    constexpr int RING = PF + 1;
+    static_assert(NSTEP % RING == 0, "ring slot bookkeeping assumes NSTEP % RING == 0");
+    static_assert(MT * NT * 4 <= NSTEP, "the trickle epilogue must fit into one chunk");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int nct = a.cout / (WN * NT * 32);
+    const int total = tiles * nct * a.n;
+    const int G = gridDim.x;
+    const int nchunks = a.cin / KC;
+    const int tile_bytes = nchunks * NSTEP * 1024;
+    const unsigned img_bytes = (unsigned)a.Hs * a.Ws * a.cin * 4u;
+    const rsrc_t wsr = make_rsrc(a.wpk, (unsigned)a.cin * a.cout * 36u);
+    const int wvo = lane * 16;
+    const int a_base = ((wm * MT) * HW_ + li) * LSTR + lh * 4;
+
+    auto decode = [&](int t) {
+        TileId r;
+        const int pt = t % tiles;
+        int q = t / tiles;
+        r.ct = q % nct;
+        r.img = q / nct;
+        r.tx0 = (pt % a.tiles_x) * TW;
+        r.ty0 = (pt / a.tiles_x) * TH;
+        return r;
+    };
+    auto stream_base = [&](const TileId& t) { return ((t.ct * WN + wn) * NT) * tile_bytes; };
+    auto src_of = [&](const TileId& t) { return make_rsrc(a.in + (size_t)t.img * a.Hs * a.Ws * a.cin, img_bytes); };
+    auto load_bias = [&](const TileId& t, float (&b)[NT]) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[n] = a.bias[((t.ct * WN + wn) * NT + n) * 32 + li];
+    };
+    auto out_addr = [&](const TileId& t) {
+        OutAddr o;
+        const size_t opix = a.pool_out ? (size_t)((a.H + 1) >> 1) * ((a.W + 1) >> 1) : (size_t)a.H * a.W;
+        o.rs = make_rsrc(a.out + (size_t)t.img * opix * a.cout, (unsigned)(opix * a.cout * 4));
+        o.lane_off = (((a.pool_out ? 2 : 4) * lh) * a.cout + ((t.ct * WN + wn) * NT) * 32 + li) * 4;
+        o.xlim = a.W - t.tx0 - 4 * lh;
+        return o;
+    };
+
+    int t = blockIdx.x;
+    if (t >= total) return;
+    TileId cur = decode(t);
+
+    Stager st;
+    st.init(tid, cur.ty0, cur.tx0, a.H, a.W, a.Hs, a.Ws, a.cin);
+    int wso = stream_base(cur);
+    f32x4 bq[RING][NT];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bq[p][n] = buf_load4(wsr, wvo, wso + n * tile_bytes + p * 1024);
+    st.load(src_of(cur), 0);
+    st.store(smem, tid);
+    __syncthreads();
+    int gc = 0;   // global chunk counter: LDS buffer parity
+
+    f32x16 accA[MT][NT], accB[MT][NT];
+    float biasA[NT], biasB[NT];
+    TileId prev = cur;
+    bool have_prev = false;
+
+    // One tile: accumulate into acc_cur; during chunk 0 trickle out acc_prev (the previous tile's result).
+    auto process = [&](f32x16 (&acc_cur)[MT][NT], float (&bias_cur)[NT], const f32x16 (&acc_prev)[MT][NT],
+                       const float (&bias_prev)[NT]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_cur[m][n][r] = 0.f;
+        load_bias(cur, bias_cur);
+        const int t_next = t + G;
+        const bool has_next = t_next < total;
+        const TileId nxt = decode(has_next ? t_next : t);
+        const int wso_next = stream_base(nxt);
+        const rsrc_t src_cur = src_of(cur);
+        const OutAddr oprev = out_addr(prev);
+        for (int c = 0; c < nchunks; ++c) {
+            const bool last = c + 1 == nchunks;
+            const float* sbuf = smem + (gc & 1) * BUF + a_base;
+            const bool stage = !last || has_next;
+            if (!last) {
+                st.load(src_cur, (c + 1) * KC * 4);
+            } else if (has_next) {
+                st.init(tid, nxt.ty0, nxt.tx0, a.H, a.W, a.Hs, a.Ws, a.cin);
+                st.load(src_of(nxt), 0);
+            }
+            // weight records past this chunk: the next chunk of this tile, or the first records of the next tile
+            const int wnext = last ? wso_next - NSTEP * 1024 : wso;
+            const bool trickle = have_prev && c == 0;
+            f32x4 aq[2][MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) aq[0][m] = *(const f32x4*)(sbuf + (m * HW_) * LSTR);
+            auto step = [&](auto KK) {
+                constexpr int k = decltype(KK)::value;
+                if constexpr (k + 1 < NSTEP) {
+                    constexpr int tp = (k + 1) >> 1, g = (k + 1) & 1;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        aq[(k + 1) & 1][m] = *(const f32x4*)(sbuf + ((m + tp / 3) * HW_ + (tp % 3)) * LSTR + g * 8);
+                }
+                constexpr int pos = k + PF;
+                const int wb = (pos < NSTEP ? wso : wnext) + pos * 1024;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bq[pos % RING][n] = buf_load4(wsr, wvo, wb + n * tile_bytes);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc_cur[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[k & 1][m][s], bq[k % RING][n][s], acc_cur[m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (trickle) {
+                    if (a.pool_out) trickle_store_pooled<MT, NT, WN, k>(a, acc_prev, bias_prev, prev, oprev, wm);
+                    else trickle_store<MT, NT, WN, k>(a, acc_prev, bias_prev, prev, oprev, wm);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            [&]<int... K>(std::integer_sequence<int, K...>) { (step(std::integral_constant<int, K>{}), ...); }
+            (std::make_integer_sequence<int, NSTEP>{});
+            wso = last ? wso_next : wso + NSTEP * 1024;
+            if (stage) st.store(smem + ((gc + 1) & 1) * BUF, tid);
+            __syncthreads();
+            ++gc;
+        }
+        prev = cur;
+        have_prev = true;
+        t = t_next;
+        cur = nxt;
+        return has_next;
+    };
+
+    // final flush of a block's last tile (all elements at once)
+    auto flush = [&](const f32x16 (&acc)[MT][NT], const float (&bias)[NT]) {
+        const OutAddr o = out_addr(prev);
+        [&]<int... K>(std::integer_sequence<int, K...>) {
+            ((a.pool_out ? trickle_store_pooled<MT, NT, WN, K>(a, acc, bias, prev, o, wm)
+                         : trickle_store<MT, NT, WN, K>(a, acc, bias, prev, o, wm)), ...);
+        }(std::make_integer_sequence<int, MT * NT * 4>{});
+    };
+
+    while (true) {
+        if (!process(accA, biasA, accB, biasB)) { flush(accA, biasA); break; }
+        if (!process(accB, biasB, accA, biasA)) { flush(accB, biasB); break; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // First layer: conv0 (1x1) folded into conv1_1 (3 -> 64), NCHW image in, NHWC out, ReLU.
 // im2col of the 8x32 tile into LDS ([256 px][32 k], stride 36 floats), then 4 k-groups of MFMA.
 // ---------------------------------------------------------------------------------------------
@@ -546,6 +806,34 @@ static int launch_cfg(ConvArgs a, hipStream_t s) {
     return check_launch("conv3x3");
 }
 
+template <int MODE, int WM, int WN, int MT, int NT, int PF>
+static int launch_persist(ConvArgs a, hipStream_t s) {
+    constexpr int TH = WM * MT, BN = WN * NT * 32;
+    if (a.cout % BN) { set_error("conv3x3: cout %d not a multiple of %d", a.cout, BN); return -1; }
+    if (a.pool_out && (MT % 2)) { set_error("conv3x3: this tile variant cannot fuse the output pool"); return -1; }
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    const long long total = (long long)a.tiles_x * a.tiles_y * (a.cout / BN) * a.n;
+    if (total <= 0 || total > 0x7fffffffLL) { set_error("conv3x3: bad grid %lld", total); return -1; }
+    // resident block slots of this kernel on the chip (host query, cached): the grid never exceeds them, and the
+    // tiles are dealt evenly: G = ceil(total / rounds)
+    static int slots = 0;
+    if (!slots) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_persist_kernel<MODE, WM, WN, MT, NT, PF>, WM * WN * 64, 0) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1) {
+            set_error("conv3x3: occupancy query failed");
+            return -2;
+        }
+        slots = per_cu * prop.multiProcessorCount;
+    }
+    const long long rounds = (total + slots - 1) / slots;
+    const unsigned G = (unsigned)((total + rounds - 1) / rounds);
+    hipLaunchKernelGGL((conv3x3_persist_kernel<MODE, WM, WN, MT, NT, PF>), dim3(G), dim3(WM * WN * 64), 0, s, a);
+    return check_launch("conv3x3(persistent)");
+}
+
 // Tile variants (block = WM x WN waves, wave tile = MT rows x 32 px by NT x 32 channels, PF = weight prefetch
 // depth in k-groups); measured with tools/tune_conv.py on the config-2 layer shapes:
 //   0: 8 rows x 64 ch,  4 waves of 2 rows x 64 ch, PF 5   (pool-out capable default)
@@ -553,6 +841,9 @@ static int launch_cfg(ConvArgs a, hipStream_t s) {
 //   2: 4 rows x 64 ch,  4 waves of 1 row x 64 ch, PF 5    (best without output pool; 2x the blocks for small maps)
 //   3: as 0 with PF 2 (round-1 baseline, kept for A/B runs)
 //   4: 4 rows x 64 ch,  2 waves of 2 rows x 64 ch, PF 2   (pool-out on small maps)
+//   5: PERSISTENT form of 3 (conv3x3_persist_kernel: resident blocks walk the tiles, trickle epilogue)
+//   6: PERSISTENT form of 2: best on the low-K layers (cin <= 128), where the epilogue share is largest
+//      (steady-state, config-2 shapes: conv2_1 136 vs 127 TF/s, dec8 138 vs 131, dec7 140 vs 137, dec6 142 vs 140)
 //  10: DIAGNOSTIC build of 3 with clock / timeline stamps (tools/clock_probe.py); never used by the product path
 template <int MODE>
 static int launch_variant(const ConvArgs& a, int variant, hipStream_t s) {
@@ -562,17 +853,27 @@ static int launch_variant(const ConvArgs& a, int variant, hipStream_t s) {
         case 2: return launch_cfg<MODE, 4, 1, 1, 2, 0, 5, 0>(a, s);
         case 3: return launch_cfg<MODE, 4, 1, 2, 2, 0, 2, 0>(a, s);
         case 4: return launch_cfg<MODE, 2, 1, 2, 2, 0, 2, 0>(a, s);
+        case 5:   // persistent, 8 rows x 64 ch, trickle epilogue
+            if constexpr (MODE != SRC_POOL2) return launch_persist<MODE, 4, 1, 2, 2, 2>(a, s);
+            break;
+        case 6:   // persistent, 4 rows x 64 ch
+            if constexpr (MODE != SRC_POOL2) return launch_persist<MODE, 4, 1, 1, 2, 5>(a, s);
+            break;
         case 10: return launch_cfg<MODE, 4, 1, 2, 2, 0, 2, 2>(a, s);
     }
     set_error("conv3x3: unknown tile variant %d", variant);
     return -1;
 }
 
-int conv3x3_auto_variant(const ConvArgs& a) {
+int conv3x3_auto_variant(const ConvArgs& a, int src_mode) {
     const long long tiles8 = (long long)((a.W + 31) / 32) * ((a.H + 7) / 8) * a.n;
-    if (!a.pool_out) return 2;
-    if (a.cout % 128 == 0 && tiles8 * (a.cout / 128) >= 512) return 1;
-    return tiles8 * (a.cout / 64) >= 256 ? 0 : 4;
+    const bool wide_ok = a.cout % 128 == 0 && tiles8 * (a.cout / 128) >= 512;
+    if (a.pool_out) {
+        if (wide_ok) return 1;
+        return tiles8 * (a.cout / 64) >= 256 ? 0 : 4;
+    }
+    if (a.cin <= 128 && src_mode != SRC_POOL2) return 6;
+    return wide_ok ? 1 : 2;
 }
 
 int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s) {
@@ -582,7 +883,7 @@ int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s) 
         set_error("conv3x3: per-image source tensor must stay below 2 GiB (32-bit buffer offsets)");
         return -1;
     }
-    if (variant < 0) variant = conv3x3_auto_variant(a);
+    if (variant < 0) variant = conv3x3_auto_variant(a, src_mode);
     switch (src_mode) {
         case SRC_DIRECT:
             if (a.Hs != a.H || a.Ws != a.W) { set_error("conv3x3: direct mode needs Hs==H, Ws==W"); return -1; }

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--variants", type=str, default="0,1,2,3,4")
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--burst", type=int, default=10)
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
     dev = torch.device("cuda", 0)
@@ -69,10 +70,11 @@ def main():
                     continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                rt.conv3x3(x, packed, b, cout, mode, True, pool, v)
+                for _ in range(args.burst):          # back-to-back launches: steady-state clocks, no idle gaps
+                    rt.conv3x3(x, packed, b, cout, mode, True, pool, v)
                 e1.record()
                 torch.cuda.synchronize()
-                times[v].append(e0.elapsed_time(e1))
+                times[v].append(e0.elapsed_time(e1) / args.burst)
         cells = []
         for v in variants:
             if ok[v]:
