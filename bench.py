@@ -146,16 +146,19 @@ class Step:
 
     def run(self, timed=False):
         ev = []
+        self.edge_ev = []
         ev_c = make_events(11) if timed else None
         cf = rt.encode(self.content, self.enc, ev_c)
         if timed:
             ev += [(ev_c[i + 1], ev_c[i + 2]) for i in range(8)]
+            self.edge_ev.append(("conv_first(content)", ev_c[0], ev_c[1]))
         if self.style_each_step:
             ev_s = make_events(11) if timed else None
             sf = rt.encode(self.style, self.enc, ev_s)
             s_mean, s_std = rt.mean_std(sf, True)
             if timed:
                 ev += [(ev_s[i + 1], ev_s[i + 2]) for i in range(8)]
+                self.edge_ev.append(("conv_first(style)", ev_s[0], ev_s[1]))
         else:
             s_mean, s_std = self.s_mean, self.s_std
         c_mean, c_std = rt.mean_std(cf, True)
@@ -168,6 +171,7 @@ class Step:
         out = rt.decode(g, self.dec, ev_d)
         if timed:
             ev += [(ev_d[i], ev_d[i + 1]) for i in range(8)]
+            self.edge_ev.append(("conv_last", ev_d[8], ev_d[9]))
         if self.config == 5:
             size = (self.h, self.w)
             out = rt.mask_composite(self.content, rt.resize_bilinear(out, size), rt.resize_nearest(self.mask, size))
@@ -194,6 +198,7 @@ def measure_roofline(step, reps):
         _, ev = step.run(timed=True)
         torch.cuda.synchronize()
         d = [a.elapsed_time(b) for a, b in ev]
+        step.edge_ms = {name: a.elapsed_time(b) for name, a, b in step.edge_ev}
         per_layer = [x + y for x, y in zip(per_layer, d)]
         total_ms += sum(d)
     launches = len(flops) * reps
@@ -334,6 +339,8 @@ def main():
         if args.layers and layers:
             for i, L in enumerate(layers):
                 print(f"layer {i:2d}: {L['gflop']:8.2f} GF  {L['ms']:8.4f} ms  {L['tflops']:7.2f} TF/s", file=sys.stderr)
+            for name, ms in getattr(step, "edge_ms", {}).items():
+                print(f"{name}: {ms:.4f} ms", file=sys.stderr)
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()
