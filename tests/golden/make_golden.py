@@ -97,6 +97,11 @@ def main():
             out_a07=test.style_transfer_simple(vgg, dec, c, s, 0.7).numpy(),
             meta=np.array([31, 2, 40, 56, 32, 2, 33, 47]),
         )
+    # ---- case D: coral colour preservation (function.py:41-67; CPU tensors, reached with preserve_color=True) -----
+    src = T(synth.image(41, 1, 24, 31)[0])
+    tgt = T(synth.image(42, 1, 20, 27)[0] * 0.5 + 0.25)
+    np.savez_compressed(os.path.join(OUT, "case_d.npz"), coral=fn.coral(src, tgt).numpy(), meta=np.array([41, 24, 31, 42, 20, 27]))
+
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
