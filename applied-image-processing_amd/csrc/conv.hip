@@ -440,7 +440,6 @@ __device__ __forceinline__ void trickle_store_pooled(const ConvArgs& a, const f3
             const bool row1 = y + 1 < a.H;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                constexpr int dummy = 0; (void)dummy;
                 const int r = r0 + 2 * j;                       // even register: pixel x = tx0 + xr + 4*lh
                 const int xr = (r & 3) + 8 * (r >> 2);
                 const bool col1 = xr + 1 < o.xlim;
