@@ -194,6 +194,9 @@ def measure_roofline(step, reps):
     flops = step.conv3x3_flops()
     total_ms = 0.0
     per_layer = [0.0] * len(flops)
+    step.run()                       # back to steady state after the gather / host work in between
+    step.run(timed=True)
+    torch.cuda.synchronize()
     for _ in range(reps):
         _, ev = step.run(timed=True)
         torch.cuda.synchronize()
@@ -278,14 +281,17 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # gloo carries the host-side rendezvous (barriers, the MAX of the step time); RCCL ("nccl") carries device
+        # tensors, i.e. the final gather of the finished frames over xGMI
+        dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world)
 
     step = Step(device, config=args.config, seed_offset=rank, size=args.size, style_size=args.style_size, batch=args.batch)
     h, w, hs, ws = step.h, step.w, step.hs, step.ws
 
     def barrier():
+        torch.cuda.synchronize()                      # this rank's GPU work is done ...
         if use_dist:
-            dist.barrier()
+            dist.all_reduce(torch.zeros(1))           # ... and so is everybody else's (host rendezvous, gloo)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -297,27 +303,32 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
 
     # final gather of the finished uint8 frames to rank 0 (outside the timed region)
-    gather_ms = None
+    gather_ms, gather_via = None, None
     u8 = rt.quantize_u8(out)
-    if world > 1 or "RANK" in os.environ:
+    if use_dist:
         torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        allf = sh.gather_frames(u8, world * args.batch, dst=0)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        if rank == 0:
+        for via in ("rccl", "gloo"):
+            try:
+                g0 = time.perf_counter()
+                allf = sh.gather_frames(u8 if via == "rccl" else u8.cpu(), world * args.batch, dst=0)
+                torch.cuda.synchronize()
+                gather_ms, gather_via = (time.perf_counter() - g0) * 1e3, via
+                break
+            except Exception as e:       # the harness must still report the compute numbers if RCCL cannot start
+                print(f"[bench] final gather over {via} failed on rank {rank}: {e}", file=sys.stderr)
+        if rank == 0 and gather_via:
             assert allf.shape[0] == world * args.batch
 
     result = None
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * h * w / 1e6 / (dt / args.steps)
-        roof, layers = measure_roofline(step, 3)
+        roof, layers = measure_roofline(step, 5)
         result = {
             "metric": "stylized Mpixels/sec, AdaIN forward (encode content + encode style + AdaIN + decode)",
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -331,6 +342,7 @@ def main():
         result["step_tflops"] = round(step.flops_per_step() / (dt / args.steps) / 1e12 * world, 2)
         if gather_ms is not None:
             result["final_gather_ms"] = round(gather_ms, 3)
+            result["final_gather_transport"] = gather_via
         if world == 1 and not args.no_cpu and args.config == 2 and args.batch == 1:
             cb, psnr, rel = cpu_baseline(h, w, hs, ws, out)
             result["cpu_baseline"] = cb
@@ -343,7 +355,7 @@ def main():
                 print(f"{name}: {ms:.4f} ms", file=sys.stderr)
         print(json.dumps(result), flush=True)
     if use_dist:
-        dist.barrier()
+        dist.all_reduce(torch.zeros(1))
         dist.destroy_process_group()
 
 
