@@ -847,6 +847,7 @@ static int launch_persist(ConvArgs a, hipStream_t s) {
 //   5: PERSISTENT form of 3 (conv3x3_persist_kernel: resident blocks walk the tiles, trickle epilogue)
 //   6: PERSISTENT form of 2: best on the low-K layers (cin <= 128), where the epilogue share is largest
 //      (steady-state, config-2 shapes: conv2_1 136 vs 127 TF/s, dec8 138 vs 131, dec7 140 vs 137, dec6 142 vs 140)
+//   7: 8 rows x 64 ch, 8 waves (4x2) of 2 rows x 32 ch, PF 5 (pool-out capable; best at cout = 64)
 //  10: DIAGNOSTIC build of 3 with clock / timeline stamps (tools/clock_probe.py); never used by the product path
 template <int MODE>
 static int launch_variant(const ConvArgs& a, int variant, hipStream_t s) {
@@ -862,6 +863,8 @@ static int launch_variant(const ConvArgs& a, int variant, hipStream_t s) {
         case 6:   // persistent, 4 rows x 64 ch
             if constexpr (MODE != SRC_POOL2) return launch_persist<MODE, 4, 1, 1, 2, 5>(a, s);
             break;
+        case 7:   // 8 rows x 64 ch, 8 waves (4x2) of 2 rows x 32 ch: best pool-out form at cout = 64 (conv1_2: 139 vs 135 TF/s)
+            return launch_cfg<MODE, 4, 2, 2, 1, 0, 5, 0>(a, s);
         case 10: return launch_cfg<MODE, 4, 1, 2, 2, 0, 2, 2>(a, s);
     }
     set_error("conv3x3: unknown tile variant %d", variant);
@@ -873,7 +876,7 @@ int conv3x3_auto_variant(const ConvArgs& a, int src_mode) {
     const bool wide_ok = a.cout % 128 == 0 && tiles8 * (a.cout / 128) >= 512;
     if (a.pool_out) {
         if (wide_ok) return 1;
-        return tiles8 * (a.cout / 64) >= 256 ? 0 : 4;
+        return tiles8 * (a.cout / 64) >= 256 ? 7 : 4;
     }
     if (a.cin <= 128 && src_mode != SRC_POOL2) return 6;
     return wide_ok ? 1 : 2;

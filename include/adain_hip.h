@@ -123,7 +123,7 @@ int adain_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, adain_
  * producer fused into the input gather (src_mode) and/or the max-pool behind this layer fused into the
  * epilogue (pool_out != 0: out is [n][ceil(h/2)][ceil(w/2)][cout]).  (h, w) = conv output size before any
  * output pool; (hs, ws) = source size.  cin % 16 == 0, cout % 64 == 0.  variant < 0 selects the tile shape
- * automatically; 0..6 force one (csrc/conv.hip, launch_variant; 5 and 6 are the persistent kernels). */
+ * automatically; 0..7 force one (csrc/conv.hip, launch_variant; 5 and 6 are the persistent kernels). */
 size_t adain_conv3x3_packed_floats(int cin, int cout);
 int adain_conv3x3_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
 int adain_conv3x3(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,

@@ -83,7 +83,7 @@ def test_conv3x3_vs_oracle(rt, mode, shape):
     close(out2.permute(0, 3, 1, 2), F.conv2d(F.pad(src, (1, 1, 1, 1), mode="reflect"), w, b))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("shape", [(1, 64, 128, 19, 45), (2, 128, 128, 8, 33), (3, 64, 64, 70, 100)])
 def test_conv3x3_tile_variants_and_fused_output_pool(rt, variant, shape):
     n, cin, cout, h, w = shape
