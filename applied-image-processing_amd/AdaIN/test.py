@@ -104,55 +104,52 @@ def _load_into(module, path, tag):
 
 
 # ---------------------------------------------------------------------------------------------------------
+def _singletons(device, vgg_str=None, decoder_str=None):
+    """The module-level encoder / decoder (net.vgg, net.decoder) in eval mode on ``device`` with the checkpoints at the
+    given paths loaded (once per file version; the reference re-reads both files on every call, test.py:183-184)."""
+    enc, dec = net.vgg.eval(), net.decoder.eval()
+    if vgg_str is not None:
+        _load_into(enc, vgg_str, "vgg")
+    if decoder_str is not None:
+        _load_into(dec, decoder_str, "decoder")
+    return enc.to(device), dec.to(device)
+
+
+def _as_batch(img, size, crop, device, rgb_only=False):
+    """PIL image -> [1,C,H,W] float tensor on ``device`` through ``test_transform(size, crop)``."""
+    x = test_transform(size, crop)(img).to(device).unsqueeze(0)
+    return x[:, :3] if (rgb_only and x.shape[1] == 4) else x
+
+
 def get_style_embeddings(
     style_img,
     vgg_str="Style_3DGS/AdaIN/models/vgg_normalised.pth",
     style_size=512,
     crop=False,
 ):
-    """relu4_1 features of the style image, [1,512,h,w] on the GPU (test.py:27-49)."""
+    """relu4_1 features of the style image, [1,512,h,w] on the GPU (reference test.py:27-49; an alpha channel of
+    the style is dropped, :46-47).  No ``no_grad`` needed: the HIP path builds no autograd graph."""
     device = _device()
-    vgg = net.vgg
-    vgg.eval()
-    _load_into(vgg, vgg_str, "vgg")
-    vgg.to(device)
-
-    style_tf = test_transform(style_size, crop)
-    style = style_tf(style_img)
-    style = style.to(device).unsqueeze(0)
-
-    # might have alpha channel
-    if style.shape[1] == 4:
-        style = style[:, :3, :, :]
-    return vgg(style)
+    enc, _ = _singletons(device, vgg_str=vgg_str)
+    return enc(_as_batch(style_img, style_size, crop, device, rgb_only=True))
 
 
 def style_transfer(vgg, decoder, content, style, depth_map, alpha=1.0, offset=0.15, prominence=20):
-    """Depth-aware transfer (test.py:52-71): decoder(AdaIN*(1-P) + content_f*P).  ``alpha`` is asserted
-    but unused, as in the reference."""
+    """Depth-aware transfer (reference test.py:52-71): ``decoder(AdaIN * (1 - P) + content_f * P)`` with the
+    strength map P from ``compute_stylization_strength_map``.  ``alpha`` is range-checked and otherwise unused,
+    exactly as in the reference; a 4-channel style loses its alpha channel."""
     assert 0.0 <= alpha <= 1.0
     assert 0.0 <= offset <= 1.0
-    content_f = vgg(content)
-
-    # might have alpha channel
-    if style.shape[1] == 4:
-        style = style[:, :3, :, :]
-    style_f = vgg(style)
-
-    # compute P
-    _, _, Hc, Wc = content_f.shape
-    P = compute_stylization_strength_map(depth_map, (Hc, Wc), offset, prominence)
-    feat = _adain_blend(content_f, style_f, pmap=P)
-    return decoder(feat)
+    f_content = vgg(content)
+    f_style = vgg(style[:, :3, :, :] if style.shape[1] == 4 else style)
+    strength = compute_stylization_strength_map(depth_map, tuple(f_content.shape[2:]), offset, prominence)
+    return decoder(_adain_blend(f_content, f_style, pmap=strength))
 
 
 def style_transfer_simple(vgg, decoder, content, style, alpha=0.5):
-    """decoder(AdaIN*alpha + content_f*(1-alpha)) (test.py:74-81)."""
+    """``decoder(AdaIN * alpha + content_f * (1 - alpha))`` (reference test.py:74-81)."""
     assert 0.0 <= alpha <= 1.0
-    content_f = vgg(content)
-    style_f = vgg(style)
-    feat = _adain_blend(content_f, style_f, alpha=alpha)
-    return decoder(feat)
+    return decoder(_adain_blend(vgg(content), vgg(style), alpha=alpha))
 
 
 def _adain_blend(content_f, style_f, alpha=None, pmap=None):
@@ -237,58 +234,34 @@ def adain_inference(
     depth_map=None,
 ):
     """Stylise one content image with one style image and save it; returns the output ``Path``
-    (test.py:153-247).  ``depth_map`` (extra, keyword-only in practice) supplies a precomputed proximity
-    map [H0,W0] for ``use_depth=True`` instead of calling the depth provider."""
+    (reference test.py:153-247; same parameters, defaults and return value).  ``depth_map`` (an addition, use it by
+    keyword) supplies a precomputed proximity map [H0,W0] for ``use_depth=True`` instead of the depth provider."""
     device = _device()
+    out_dir = Path(output)
+    out_dir.mkdir(exist_ok=True, parents=True)
+    enc, dec = _singletons(device, vgg_str, decoder_str)
 
-    output_dir = Path(output)
-    output_dir.mkdir(exist_ok=True, parents=True)
-
-    decoder = net.decoder
-    vgg = net.vgg
-    decoder.eval()
-    vgg.eval()
-    _load_into(decoder, decoder_str, "decoder")
-    _load_into(vgg, vgg_str, "vgg")
-    vgg.to(device)
-    decoder.to(device)
-
-    content_tf = test_transform(content_size, crop)
-    style_tf = test_transform(style_size, crop)
-
-    # process one content and one style
-    if type(content_img) == str:
-        content_img = Image.open(content_img)
-    if type(style_img) == str:
-        style_img = Image.open(str(style_img))
-
-    content = content_tf(content_img)
-    style = style_tf(style_img)
-    if preserve_color:
+    pil_content = Image.open(content_img) if type(content_img) == str else content_img
+    pil_style = Image.open(str(style_img)) if type(style_img) == str else style_img
+    content = test_transform(content_size, crop)(pil_content)
+    style = test_transform(style_size, crop)(pil_style)
+    if preserve_color:                       # CORAL runs on the host tensors, as in the reference (test.py:201-202)
         style = coral(style, content)
-    style = style.to(device).unsqueeze(0)
-    content = content.to(device).unsqueeze(0)
+    content, style = content.to(device).unsqueeze(0), style.to(device).unsqueeze(0)
 
-    with torch.no_grad():
-        if use_depth:
-            depth_map_est = depth_map if depth_map is not None else midas_depth_map_est(content_img)
-            output_img = style_transfer(vgg, decoder, content, style, depth_map_est, alpha, depth_offset, depth_prominence)
-        else:
-            output_img = style_transfer_simple(vgg, decoder, content, style, alpha)
+    if use_depth:
+        proximity = depth_map if depth_map is not None else midas_depth_map_est(pil_content)
+        result = style_transfer(enc, dec, content, style, proximity, alpha, depth_offset, depth_prominence)
+    else:
+        result = style_transfer_simple(enc, dec, content, style, alpha)
+    if content_mask is not None:
+        result = composite_with_mask(content, result, content_mask)
+    result = result[:, :3, :, :]             # an RGBA result keeps its colour planes only (test.py:240-241)
 
-        if content_mask is not None:
-            stylized_tensor = composite_with_mask(content, output_img, content_mask)
-        else:
-            stylized_tensor = output_img
-
-    if stylized_tensor.shape[1] == 4:  # If it has 4 channels (RGBA)
-        stylized_tensor = stylized_tensor[:, :3, :, :]
-
-    output_path = output_dir / f"{file_name}{save_ext}"
-    save_image(stylized_tensor, str(output_path))
-    print(f"Image saved to {output_path}")
-
-    return output_path
+    target = out_dir / f"{file_name}{save_ext}"
+    save_image(result, str(target))
+    print(f"Image saved to {target}")
+    return target
 
 
 def composite_with_mask(content, output_img, content_mask):
