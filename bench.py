@@ -263,6 +263,7 @@ def main():
     ap.add_argument("--style-size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--pcie", action="store_true", help="also report the rate with the frame crossing PCIe both ways (never `value`)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     args = ap.parse_args()
 
@@ -343,6 +344,20 @@ def main():
         if gather_ms is not None:
             result["final_gather_ms"] = round(gather_ms, 3)
             result["final_gather_transport"] = gather_via
+        if args.pcie:
+            # host buffers at the boundary: pinned fp32 frame in, pinned uint8 frame out, copies on the same stream
+            host_in = step.content.cpu().pin_memory()
+            host_out = torch.empty((args.batch, out.shape[2], out.shape[3], 3), dtype=torch.uint8).pin_memory()
+            torch.cuda.synchronize()
+            p0 = time.perf_counter()
+            for _ in range(args.steps):
+                step.content.copy_(host_in, non_blocking=True)
+                o = step.run()
+                host_out.copy_(rt.quantize_u8(o), non_blocking=True)
+            torch.cuda.synchronize()
+            pdt = (time.perf_counter() - p0) / args.steps
+            result["pcie_inclusive"] = {"value": round(args.batch * h * w / 1e6 / pdt, 3), "unit": "Mpixels/s",
+                                        "ms_per_step": round(pdt * 1e3, 4), "what": "pinned fp32 frame H2D + forward + uint8 D2H per step"}
         if world == 1 and not args.no_cpu and args.config == 2 and args.batch == 1:
             cb, psnr, rel = cpu_baseline(h, w, hs, ws, out)
             result["cpu_baseline"] = cb
