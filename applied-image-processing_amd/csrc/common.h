@@ -25,6 +25,7 @@ struct ConvArgs {
     int cin, cout;
     int relu;
     int pool_out;       // 1: write only MaxPool2d(2,2,ceil_mode=True)(output), [n][ceil(H/2)][ceil(W/2)][cout]
+    int xcd_order;      // 1: XCD-aware block -> tile order (speed only)
     int tiles_x, tiles_y;
     unsigned long long* dbg;   // diagnostic builds only (clock stamps); nullptr in production
 };

@@ -21,6 +21,7 @@
 //     the group, k-step s uses element s), identically for A and B, so each b128 feeds 4 MFMAs.
 //   fp32 MFMA runs at the fp32 vector rate (64 cycles per 32x32x2), so HBM, L2 and LDS traffic are
 //   far below their limits; the kernel is bound by MFMA issue.
+#include <stdlib.h>
 #include <utility>
 
 #include "common.h"
@@ -208,12 +209,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma_kernel(ConvArgs a) 
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
-    int bid = blockIdx.x;
     const int tiles = a.tiles_x * a.tiles_y;
-    const int pt = bid % tiles; bid /= tiles;
     const int nct = a.cout / (WN * NT * 32);
-    const int ct = bid % nct;
-    const int img = bid / nct;
+    int pt, ct, img;
+    if (a.xcd_order) {
+        // XCD-aware order (speed only): workgroups are dealt round-robin to the 8 XCDs, so block b and b + 8 share an
+        // L2.  Give each XCD a contiguous range of the (pixel tile, channel tile) list with the channel tile fastest:
+        // the channel tiles of one pixel tile then run back to back on ONE XCD and the halo is fetched from HBM once
+        // and re-read from that L2, instead of once per channel tile.
+        const int nb = gridDim.x;
+        int lid = blockIdx.x;
+        if ((nb & 7) == 0) lid = (lid & 7) * (nb >> 3) + (lid >> 3);
+        ct = lid % nct; lid /= nct;
+        pt = lid % tiles;
+        img = lid / tiles;
+    } else {
+        int bid = blockIdx.x;
+        pt = bid % tiles; bid /= tiles;
+        ct = bid % nct;
+        img = bid / nct;
+    }
     const int tx0 = (pt % a.tiles_x) * TW, ty0 = (pt / a.tiles_x) * TH;
     const int nchunks = a.cin / KC;
 
@@ -489,10 +504,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_persist_kernel(ConvAr
 
     auto decode = [&](int t) {
         TileId r;
-        const int pt = t % tiles;
-        int q = t / tiles;
-        r.ct = q % nct;
-        r.img = q / nct;
+        int pt;
+        if (a.xcd_order) {          // channel tile fastest (see conv3x3_mfma_kernel)
+            r.ct = t % nct;
+            const int q = t / nct;
+            pt = q % tiles;
+            r.img = q / tiles;
+        } else {
+            pt = t % tiles;
+            const int q = t / tiles;
+            r.ct = q % nct;
+            r.img = q / nct;
+        }
         r.tx0 = (pt % a.tiles_x) * TW;
         r.ty0 = (pt / a.tiles_x) * TH;
         return r;
@@ -513,6 +536,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_persist_kernel(ConvAr
     };
 
     int t = blockIdx.x;
+    if (a.xcd_order && (G & 7) == 0) t = (t & 7) * (G >> 3) + (t >> 3);   // blocks of one XCD walk neighbouring tiles
     if (t >= total) return;
     TileId cur = decode(t);
 
@@ -890,16 +914,19 @@ int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s) 
         return -1;
     }
     if (variant < 0) variant = conv3x3_auto_variant(a, src_mode);
+    ConvArgs b = a;
+    static const int xcd_env = getenv("ADAIN_XCD_ORDER") ? atoi(getenv("ADAIN_XCD_ORDER")) : 1;
+    b.xcd_order = xcd_env;
     switch (src_mode) {
         case SRC_DIRECT:
             if (a.Hs != a.H || a.Ws != a.W) { set_error("conv3x3: direct mode needs Hs==H, Ws==W"); return -1; }
-            return launch_variant<SRC_DIRECT>(a, variant, s);
+            return launch_variant<SRC_DIRECT>(b, variant, s);
         case SRC_UP2X:
             if (a.H != 2 * a.Hs || a.W != 2 * a.Ws) { set_error("conv3x3: up2x mode needs H==2Hs, W==2Ws"); return -1; }
-            return launch_variant<SRC_UP2X>(a, variant, s);
+            return launch_variant<SRC_UP2X>(b, variant, s);
         case SRC_POOL2:
             if (a.H != (a.Hs + 1) / 2 || a.W != (a.Ws + 1) / 2) { set_error("conv3x3: pool mode needs H==ceil(Hs/2), W==ceil(Ws/2)"); return -1; }
-            return launch_variant<SRC_POOL2>(a, variant, s);
+            return launch_variant<SRC_POOL2>(b, variant, s);
     }
     set_error("conv3x3: unknown src_mode %d", src_mode);
     return -1;
