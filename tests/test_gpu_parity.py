@@ -340,3 +340,53 @@ def test_edge_sizes_layouts_and_dtypes(rt, nets, weights):
     c = T(synth.image(94, 2, 37, 99))
     with torch.no_grad():
         close(vgg(c.cuda()), O.encode(vgg_sd, c))
+
+
+def test_batched_depth_and_mask_broadcast_rules(rt, weights):
+    """Batch extensions of the C ABI (style_n / pmap_n / mask_n in {1, n}) against per-frame reference calls."""
+    from applied_image_processing_amd.engine import AdaINEngine
+
+    vgg_sd, dec_sd = weights
+    e = AdaINEngine(vgg_sd, dec_sd, "cuda:0").set_style(T(synth.image(4, 1, 64, 64)).cuda())
+    frames = T(np.concatenate([synth.image(120 + i, 1, 48, 80) for i in range(2)]))
+    depths = [T(synth.smooth_depth(130 + i, 48, 80)) for i in range(2)]
+    out = e.stylize_depth(frames.cuda(), [d.cuda() for d in depths], 0.2, 12)
+    s = T(synth.image(4, 1, 64, 64))
+    for i in range(2):
+        with torch.no_grad():
+            ref = O.style_transfer(vgg_sd, dec_sd, frames[i:i + 1], s, depths[i], 1.0, 0.2, 12)
+        close(out[i:i + 1], ref, 5e-4, 5e-4)
+    # per-frame masks [n,1,h,w] and one shared mask [1,3,h,w]
+    m_n = (T(synth.image(140, 2, 20, 30, c=1)) > 0.5).float()
+    m_1 = (T(synth.image(141, 1, 48, 80)) > 0.5).float()
+    for m in (m_n, m_1):
+        got = e.composite(frames.cuda(), out, m.cuda())
+        for i in range(2):
+            want = O.mask_composite(frames[i:i + 1], out[i:i + 1].cpu(), m[min(i, m.shape[0] - 1)])
+            close(got[i:i + 1], want, 1e-5, 1e-5)
+    with pytest.raises(rt.AdainHipError):
+        rt.mask_composite(frames.cuda(), out, torch.zeros(2, 2, 48, 80, device="cuda"))   # mask channels must be 1 or 3
+
+
+def test_statistics_edge_cases(rt):
+    from applied_image_processing_amd.AdaIN import function as fn
+
+    # one pixel per channel: torch's unbiased variance is NaN (0/0); the kernels reproduce that
+    x = T(synth.uniform_sym(150, (1, 8, 1, 1), 1.0))
+    m, s = fn.calc_mean_std(x.cuda())
+    rm, rs = O.calc_mean_std(x)
+    close(m, rm, 1e-6, 1e-7)
+    assert torch.isnan(s).all() and torch.isnan(rs).all()
+    # a large map through the multi-block NHWC reduction, both layouts bitwise identical run to run
+    y = T(synth.uniform_sym(151, (1, 512, 96, 160), 3.0)).cuda().contiguous(memory_format=torch.channels_last)
+    m1, s1 = fn.calc_mean_std(y)
+    m2, s2 = fn.calc_mean_std(y)
+    assert torch.equal(m1, m2) and torch.equal(s1, s2)
+    rm, rs = O.calc_mean_std(y.cpu().contiguous())
+    close(m1, rm, 1e-5, 1e-6)
+    close(s1, rs, 1e-5, 1e-6)
+    # strength map: large target, down- and up-scaling, against torch
+    d = T(synth.smooth_depth(152, 300, 500))
+    for size in ((600, 1000), (37, 61)):
+        p = rt.strength_map(d.cuda(), size[0], size[1], 0.1, 15.0)
+        close(p, O.compute_stylization_strength_map(d, size, 0.1, 15.0), 1e-4, 3e-5)
