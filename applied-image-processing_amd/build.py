@@ -11,7 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libadain_hip.so")
-SOURCES = ["conv.hip", "stats.hip", "pixel.hip", "api.hip"]
+SOURCES = ["conv.hip", "conv_wino.hip", "stats.hip", "pixel.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -32,7 +32,7 @@ def _newer(target, deps):
 def build(force=False, verbose=False):
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(INC, "adain_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_utils.h"), os.path.join(INC, "adain_hip.h")]
     hipcc = _hipcc()
     jobs = []
     objs = []

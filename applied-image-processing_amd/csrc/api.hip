@@ -1,6 +1,7 @@
 // extern "C" boundary (include/adain_hip.h) and the encoder / decoder layer schedules.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/adain_hip.h"
 #include "common.h"
@@ -32,33 +33,59 @@ static const Layer DEC[8] = {{512, 256, SRC_DIRECT, 0}, {256, 256, SRC_UP2X, 0},
 static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
 constexpr size_t FIRST_W = 2 * 4 * 64 * 4, FIRST_B = 64, LAST_W = 4 * 9 * 4 * 4 * 3, LAST_B = 3;
 
-// packed layout: [first w][first b] then per generic layer [w][b], every block 256-B aligned
-static size_t enc_offsets(size_t* w_off, size_t* b_off, size_t* first_b) {
+// packed layout: [first w][first b] then per generic layer [w direct][b][w winograd], every block 256-B aligned.
+// Both weight forms are kept (28 MB + 50 MB): the Winograd kernel is the default for every generic 3x3 layer,
+// ADAIN_WINOGRAD=0 switches a process back to the direct implicit GEMM (A/B runs, bit-different but equally valid).
+struct Offsets { size_t w[8], b[8], ww[8], first_b, last_w, last_b, total; };
+static Offsets enc_offsets() {
+    Offsets f{};
     size_t o = 0;
     o += align64(FIRST_W);
-    *first_b = o;
+    f.first_b = o;
     o += align64(FIRST_B);
     for (int i = 0; i < 8; ++i) {
-        w_off[i] = o;
+        f.w[i] = o;
         o += align64((size_t)ENC[i].cin * ENC[i].cout * 9);
-        b_off[i] = o;
+        f.b[i] = o;
         o += align64(ENC[i].cout);
+        f.ww[i] = o;
+        o += align64((size_t)ENC[i].cin * ENC[i].cout * 16);
     }
-    return o;
+    f.total = o;
+    return f;
 }
-static size_t dec_offsets(size_t* w_off, size_t* b_off, size_t* last_w, size_t* last_b) {
+static Offsets dec_offsets() {
+    Offsets f{};
     size_t o = 0;
     for (int i = 0; i < 8; ++i) {
-        w_off[i] = o;
+        f.w[i] = o;
         o += align64((size_t)DEC[i].cin * DEC[i].cout * 9);
-        b_off[i] = o;
+        f.b[i] = o;
         o += align64(DEC[i].cout);
+        f.ww[i] = o;
+        o += align64((size_t)DEC[i].cin * DEC[i].cout * 16);
     }
-    *last_w = o;
+    f.last_w = o;
     o += align64(LAST_W);
-    *last_b = o;
+    f.last_b = o;
     o += align64(LAST_B);
-    return o;
+    f.total = o;
+    return f;
+}
+
+static bool use_winograd() {
+    static const bool on = !(getenv("ADAIN_WINOGRAD") && atoi(getenv("ADAIN_WINOGRAD")) == 0);
+    return on;
+}
+
+static int launch_layer(ConvArgs& a, const float* packed, const Offsets& f, int i, int src, hipStream_t s) {
+    a.bias = packed + f.b[i];
+    if (use_winograd() && src != SRC_POOL2) {
+        a.wpk = packed + f.ww[i];
+        return launch_conv3x3_wino(a, src, s);
+    }
+    a.wpk = packed + f.w[i];
+    return launch_conv3x3(a, src, -1, s);
 }
 
 static int copy_bias(const float* src, float* dst, int n, hipStream_t s) {
@@ -84,24 +111,18 @@ extern "C" {
 int adain_abi_version(void) { return ADAIN_ABI_VERSION; }
 const char* adain_last_error(void) { return g_err; }
 
-size_t adain_encoder_packed_floats(void) {
-    size_t w[8], b[8], fb;
-    return enc_offsets(w, b, &fb);
-}
-size_t adain_decoder_packed_floats(void) {
-    size_t w[8], b[8], lw, lb;
-    return dec_offsets(w, b, &lw, &lb);
-}
+size_t adain_encoder_packed_floats(void) { return enc_offsets().total; }
+size_t adain_decoder_packed_floats(void) { return dec_offsets().total; }
 
 int adain_encoder_pack(const float* const* w, const float* const* b, float* packed, adain_stream_t stream) {
     if (!w || !b || !packed) { set_error("encoder_pack: null pointer"); return ADAIN_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
-    size_t wo[8], bo[8], fb;
-    enc_offsets(wo, bo, &fb);
-    RET_IF(launch_pack_conv_first(w[0], b[0], w[1], b[1], packed, packed + fb, s));
+    const Offsets f = enc_offsets();
+    RET_IF(launch_pack_conv_first(w[0], b[0], w[1], b[1], packed, packed + f.first_b, s));
     for (int i = 0; i < 8; ++i) {
-        RET_IF(launch_pack_conv3x3(w[i + 2], packed + wo[i], ENC[i].cin, ENC[i].cout, s));
-        RET_IF(copy_bias(b[i + 2], packed + bo[i], ENC[i].cout, s));
+        RET_IF(launch_pack_conv3x3(w[i + 2], packed + f.w[i], ENC[i].cin, ENC[i].cout, s));
+        RET_IF(launch_pack_wino(w[i + 2], packed + f.ww[i], ENC[i].cin, ENC[i].cout, s));
+        RET_IF(copy_bias(b[i + 2], packed + f.b[i], ENC[i].cout, s));
     }
     return 0;
 }
@@ -109,14 +130,14 @@ int adain_encoder_pack(const float* const* w, const float* const* b, float* pack
 int adain_decoder_pack(const float* const* w, const float* const* b, float* packed, adain_stream_t stream) {
     if (!w || !b || !packed) { set_error("decoder_pack: null pointer"); return ADAIN_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
-    size_t wo[8], bo[8], lw, lb;
-    dec_offsets(wo, bo, &lw, &lb);
+    const Offsets f = dec_offsets();
     for (int i = 0; i < 8; ++i) {
-        RET_IF(launch_pack_conv3x3(w[i], packed + wo[i], DEC[i].cin, DEC[i].cout, s));
-        RET_IF(copy_bias(b[i], packed + bo[i], DEC[i].cout, s));
+        RET_IF(launch_pack_conv3x3(w[i], packed + f.w[i], DEC[i].cin, DEC[i].cout, s));
+        RET_IF(launch_pack_wino(w[i], packed + f.ww[i], DEC[i].cin, DEC[i].cout, s));
+        RET_IF(copy_bias(b[i], packed + f.b[i], DEC[i].cout, s));
     }
-    RET_IF(launch_pack_conv_last(w[8], packed + lw, s));
-    RET_IF(copy_bias(b[8], packed + lb, 3, s));
+    RET_IF(launch_pack_conv_last(w[8], packed + f.last_w, s));
+    RET_IF(copy_bias(b[8], packed + f.last_b, 3, s));
     return 0;
 }
 
@@ -159,12 +180,11 @@ int adain_encode(const float* image, float* feat, const float* packed, void* wor
     }
     if (ws_bytes < adain_encode_workspace_bytes(n, h, w)) { set_error("encode: workspace too small"); return ADAIN_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
-    size_t wo[8], bo[8], fb;
-    enc_offsets(wo, bo, &fb);
+    const Offsets f = enc_offsets();
     float* bufA = (float*)workspace;
     float* bufB = bufA + enc_buf_a(n, h, w);
     record(ev, 0, s);
-    RET_IF(launch_conv_first(image, bufA, packed, packed + fb, n, h, w, s));
+    RET_IF(launch_conv_first(image, bufA, packed, packed + f.first_b, n, h, w, s));
     record(ev, 1, s);
     const float* cur = bufA;
     int ch = h, cw = w;
@@ -172,15 +192,13 @@ int adain_encode(const float* image, float* feat, const float* packed, void* wor
         ConvArgs a{};
         a.in = cur;
         a.out = (i == 7) ? feat : (cur == bufA ? bufB : bufA);
-        a.wpk = packed + wo[i];
-        a.bias = packed + bo[i];
         a.n = n;
         a.Hs = ch; a.Ws = cw;
         a.H = ch; a.W = cw;
         a.cin = ENC[i].cin; a.cout = ENC[i].cout;
         a.relu = 1;
         a.pool_out = ENC[i].pool;
-        RET_IF(launch_conv3x3(a, ENC[i].src, -1, s));
+        RET_IF(launch_layer(a, packed, f, i, ENC[i].src, s));
         record(ev, i + 2, s);
         cur = a.out;
         if (ENC[i].pool) { ch = (ch + 1) / 2; cw = (cw + 1) / 2; }
@@ -199,8 +217,7 @@ int adain_decode(const float* feat, float* image, const float* packed, void* wor
     if (n < 1 || hc < 2 || wc < 2) { set_error("decode: feature map %dx%d too small (needs >= 2x2)", hc, wc); return ADAIN_EINVAL; }
     if (ws_bytes < adain_decode_workspace_bytes(n, hc, wc)) { set_error("decode: workspace too small"); return ADAIN_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
-    size_t wo[8], bo[8], lw, lb;
-    dec_offsets(wo, bo, &lw, &lb);
+    const Offsets f = dec_offsets();
     // buffer A (1024*hc*wc floats per image) takes the outputs of layers 0,2,4,6; buffer B (4096*hc*wc) of 1,3,5,7
     float* bufA = (float*)workspace;
     float* bufB = bufA + align64((size_t)n * hc * wc * 1024);
@@ -211,19 +228,17 @@ int adain_decode(const float* feat, float* image, const float* packed, void* wor
         ConvArgs a{};
         a.in = cur;
         a.out = (i & 1) ? bufB : bufA;
-        a.wpk = packed + wo[i];
-        a.bias = packed + bo[i];
         a.n = n;
         a.Hs = ch; a.Ws = cw;
         if (DEC[i].src == SRC_UP2X) { ch *= 2; cw *= 2; }
         a.H = ch; a.W = cw;
         a.cin = DEC[i].cin; a.cout = DEC[i].cout;
         a.relu = 1;
-        RET_IF(launch_conv3x3(a, DEC[i].src, -1, s));
+        RET_IF(launch_layer(a, packed, f, i, DEC[i].src, s));
         record(ev, i + 1, s);
         cur = a.out;
     }
-    RET_IF(launch_conv_last(cur, image, packed + lw, packed + lb, n, ch, cw, s));
+    RET_IF(launch_conv_last(cur, image, packed + f.last_w, packed + f.last_b, n, ch, cw, s));
     record(ev, 9, s);
     return 0;
 }
@@ -310,6 +325,22 @@ int adain_conv3x3(const float* in, float* out, const float* packed_w, const floa
     a.in = in; a.out = out; a.wpk = packed_w; a.bias = bias;
     a.n = n; a.H = h; a.W = w; a.Hs = hs; a.Ws = ws; a.cin = cin; a.cout = cout; a.relu = relu; a.pool_out = pool_out ? 1 : 0;
     return launch_conv3x3(a, src_mode, variant, (hipStream_t)stream);
+}
+
+size_t adain_conv3x3_wino_packed_floats(int cin, int cout) { return (size_t)cin * cout * 16; }
+
+int adain_conv3x3_wino_pack(const float* w, float* packed, int cin, int cout, adain_stream_t stream) {
+    if (!w || !packed) { set_error("conv3x3_wino_pack: null pointer"); return ADAIN_EINVAL; }
+    return launch_pack_wino(w, packed, cin, cout, (hipStream_t)stream);
+}
+
+int adain_conv3x3_wino(const float* in, float* out, const float* packed_w, const float* bias, int n, int h, int w, int hs, int ws,
+                       int cin, int cout, int src_mode, int relu, int pool_out, adain_stream_t stream) {
+    if (!in || !out || !packed_w || !bias) { set_error("conv3x3_wino: null pointer"); return ADAIN_EINVAL; }
+    ConvArgs a{};
+    a.in = in; a.out = out; a.wpk = packed_w; a.bias = bias;
+    a.n = n; a.H = h; a.W = w; a.Hs = hs; a.Ws = ws; a.cin = cin; a.cout = cout; a.relu = relu; a.pool_out = pool_out ? 1 : 0;
+    return launch_conv3x3_wino(a, src_mode, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -25,6 +25,7 @@
 #include <utility>
 
 #include "common.h"
+#include "device_utils.h"
 
 namespace adain {
 
@@ -32,32 +33,6 @@ constexpr int KC = 16;           // input channels per LDS chunk
 constexpr int LSTR = KC + 4;     // LDS pixel stride in floats (80 B)
 constexpr int TW = 32;           // tile width == MFMA M
 constexpr int HW_ = TW + 2;      // halo width
-
-__device__ __forceinline__ int reflect1(int v, int n) {
-    // ReflectionPad2d(1) index map, after clamping to [-1, n] (tiles may overhang the image).
-    v = max(-1, min(v, n));
-    v = v < 0 ? -v : v;
-    return v >= n ? 2 * n - 2 - v : v;
-}
-
-__device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) {
-    f32x4 r;
-    r.x = fmaxf(a.x, b.x); r.y = fmaxf(a.y, b.y); r.z = fmaxf(a.z, b.z); r.w = fmaxf(a.w, b.w);
-    return r;
-}
-
-// Buffer-descriptor loads: 32-bit per-lane byte offset + scalar byte offset, hardware range check
-// (out-of-range reads return 0), no 64-bit address arithmetic in the loop.
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int;
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4 buf_load4(rsrc_t r, int voff, int soff) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return __builtin_bit_cast(f32x4, v);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Weight packing (runs once per weight set, on the device).

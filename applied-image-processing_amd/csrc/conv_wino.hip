@@ -1,0 +1,302 @@
+// Winograd F(2x2, 3x3) form of the 3x3 convolution for the K-heavy layers (cin >= 128), gfx950.
+//
+// The direct implicit GEMM (conv.hip) is bound by the fp32 MFMA rate; the only lever left is fewer
+// multiplies.  F(2x2,3x3) computes a 2x2 output tile from a 4x4 input patch with 16 multiplies per
+// (cin, cout) pair instead of 36: Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A, 2.25x fewer MFMA flops.
+// In fp32 its rounding error is ~2x that of the direct form (3.9e-7 vs 1.7e-7 relative on these layers),
+// far inside the path's tolerance.
+//
+// Mapping (one workgroup of 8 waves per CU, 128 KiB of LDS):
+//   * block tile = 8 x 32 output pixels = 64 Winograd tiles (4 tile rows x 16 tile columns) x 64 channels;
+//   * the 16 transform positions xi = (i, j) are 16 independent GEMMs [64 tiles x cin] x [cin x 64].  Wave
+//     (mh, i) owns transform ROW i (its 4 positions j) for M-tile mh (32 tiles): 4 x 2 MFMA tiles of
+//     32x32 = 128 accumulator registers; v_mfma_f32_32x32x2_f32 as in the direct kernel;
+//   * A operand: per 8-channel chunk the raw reflect-padded 10 x 34 halo is staged into LDS (global ->
+//     registers -> LDS, prefetched two chunks ahead), every thread transforms one column of one patch
+//     (B^T d B: 32 adds) and writes V[xi][tile][8 ch] (row stride 48 B: conflict-free b128 reads);
+//     the transform of chunk c+1 is interleaved with the MFMAs of chunk c; one barrier per chunk;
+//   * B operand: transformed weights U = G g G^T are packed on the device once per weight set into
+//     per-lane fragment order [cout/64][row i][chunk][j][n][lane][4] and streamed straight into VGPRs
+//     (the two M-tile waves of a row share them through L1);
+//   * epilogue: each wave reduces its row (P = M A, two partial matrices), the 4 rows meet in LDS
+//     (all 128 KiB), then every lane owns one channel and finishes Y = A^T P for 8 tiles: bias, ReLU,
+//     optional 2x2 max-pool of the output (the 4 outputs of a Winograd tile ARE one pool window), stores of
+//     256 contiguous bytes per pixel.
+#include "common.h"
+#include "device_utils.h"
+
+namespace adain {
+
+constexpr int WKC = 8;                 // channels per chunk
+constexpr int WVSTR = 12;              // floats per V row (8 channels + 4 pad)
+constexpr int WTILES = 64;             // Winograd tiles per block
+constexpr int WVSTAGE = 16 * WTILES * WVSTR;          // 12288 floats
+constexpr int WHALO_W = 34, WHALO = 10 * WHALO_W;     // raw halo pixels
+constexpr int WRBUF = WHALO * WVSTR;                  // 4080 floats
+constexpr int WLDS = 32768;                           // floats (128 KiB): max(2 V + 2 raw, P exchange)
+static_assert(2 * WVSTAGE + 2 * WRBUF <= WLDS, "LDS layout");
+
+// OIHW [cout][cin][3][3] -> U = G g G^T packed as [cout/64][i 4][cin/8][j 4][n 2][lane 64][s 4]:
+//   value = U[xi = 4 i + j][cout = 64 ct + 32 n + (lane & 31)][cin = 8 chunk + 4 (lane >> 5) + s]
+__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ p, int cin, int cout) {
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    const size_t total = (size_t)cin * cout * 16;
+    const int nch = cin / WKC;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t r = idx;
+        const int s = r & 3; r >>= 2;
+        const int lane = r & 63; r >>= 6;
+        const int n = r & 1; r >>= 1;
+        const int j = r & 3; r >>= 2;
+        const int chunk = r % nch; r /= nch;
+        const int i = r & 3; r >>= 2;
+        const int ct = (int)r;
+        const int co = ct * 64 + n * 32 + (lane & 31), ci = chunk * WKC + 4 * (lane >> 5) + s;
+        const float* g = w + ((size_t)co * cin + ci) * 9;
+        float u = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) u += G[i][a] * g[a * 3 + b] * G[j][b];
+        p[idx] = u;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[WLDS];
+    float* const Vs = smem;                      // 2 stages
+    float* const Rs = smem + 2 * WVSTAGE;        // 2 raw halo buffers
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mh = wave >> 2, wi = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // block -> (pixel tile, channel tile, image), XCD-aware order as in conv.hip
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int nct = a.cout / 64;
+    int lid = blockIdx.x;
+    if (a.xcd_order && (gridDim.x & 7) == 0) lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
+    const int ct = lid % nct; lid /= nct;
+    const int pt = lid % tiles;
+    const int img = lid / tiles;
+    const int tx0 = (pt % a.tiles_x) * 32, ty0 = (pt / a.tiles_x) * 8;
+    const int nch = a.cin / WKC;
+
+    const rsrc_t src = make_rsrc(a.in + (size_t)img * a.Hs * a.Ws * a.cin, (unsigned)a.Hs * a.Ws * a.cin * 4u);
+    const rsrc_t wsr = make_rsrc(a.wpk, (unsigned)a.cin * a.cout * 64u);
+
+    // ---- raw halo staging: 680 items (pixel, quad) over 512 threads ------------------------------------------
+    int roff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = tid + k * 512;
+        const int hp = min(idx >> 1, WHALO - 1), q = idx & 1;
+        const int hy = hp / WHALO_W, hx = hp - hy * WHALO_W;
+        int y = reflect1(ty0 + hy - 1, a.H), x = reflect1(tx0 + hx - 1, a.W);
+        if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
+        roff[k] = ((y * a.Ws + x) * a.cin + q * 4) * 4;
+    }
+    f32x4 rawreg[2];
+    auto raw_load = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) rawreg[k] = buf_load4(src, roff[k], chunk * WKC * 4);
+    };
+    auto raw_store = [&](float* buf) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = tid + k * 512;
+            if (idx < WHALO * 2) *(f32x4*)(buf + (idx >> 1) * WVSTR + (idx & 1) * 4) = rawreg[k];
+        }
+    };
+
+    // ---- input transform unit of this thread: column tc of the patch of tile ut, channel quad uq ----------------
+    const int tc = tid >> 7, ut = (tid & 127) >> 1, uq = tid & 1;
+    const int u_base = ((2 * (ut >> 4)) * WHALO_W + 2 * (ut & 15)) * WVSTR + uq * 4;     // patch origin in the raw buffer
+    const int colA = tc == 0 ? 0 : 1, colB = tc == 3 ? 3 : 2;
+    const int v_base = (tc * WTILES + ut) * WVSTR + uq * 4;                             // V[xi = 4 i + tc][ut][uq*4]
+    f32x4 dA[4], dB[4], tr[4];
+    auto xf_read = [&](const float* rbuf) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dA[r] = *(const f32x4*)(rbuf + u_base + (r * WHALO_W + colA) * WVSTR);
+            dB[r] = *(const f32x4*)(rbuf + u_base + (r * WHALO_W + colB) * WVSTR);
+        }
+    };
+    auto xf_rows = [&]() {      // (d B)[r][tc]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (tc == 1) tr[r] = dA[r] + dB[r];
+            else if (tc == 2) tr[r] = dB[r] - dA[r];
+            else tr[r] = dA[r] - dB[r];
+        }
+    };
+    auto xf_write = [&](float* vbuf) {   // B^T (.) : rows t0 - t2, t1 + t2, t2 - t1, t1 - t3
+        *(f32x4*)(vbuf + v_base + 0 * 4 * WTILES * WVSTR) = tr[0] - tr[2];
+        *(f32x4*)(vbuf + v_base + 1 * 4 * WTILES * WVSTR) = tr[1] + tr[2];
+        *(f32x4*)(vbuf + v_base + 2 * 4 * WTILES * WVSTR) = tr[2] - tr[1];
+        *(f32x4*)(vbuf + v_base + 3 * 4 * WTILES * WVSTR) = tr[1] - tr[3];
+    };
+
+    // ---- MFMA operands ---------------------------------------------------------------------------------------------
+    const int a_base = ((4 * wi) * WTILES + mh * 32 + li) * WVSTR + lh * 4;   // + j * WTILES * WVSTR
+    const int wvo = lane * 16;
+    int wso = ((ct * 4 + wi) * nch) * 8192;     // byte offset of this wave's record stream: [chunk][j][n] x 1 KiB
+    constexpr int PF = 3, RING = 4;
+    f32x4 bq[RING][2];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bq[p][n] = buf_load4(wsr, wvo, wso + p * 2048 + n * 1024);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
+
+    // ---- prologue: raw chunk 0 -> V stage 0, raw chunk 1 -> raw buffer 1 ------------------------------------------
+    raw_load(0);
+    raw_store(Rs);
+    __syncthreads();
+    if (nch > 1) raw_load(1);
+    xf_read(Rs);
+    xf_rows();
+    xf_write(Vs);
+    if (nch > 1) raw_store(Rs + WRBUF);
+    __syncthreads();
+
+    for (int c = 0; c < nch; ++c) {
+        const float* Vc = Vs + (c & 1) * WVSTAGE + a_base;
+        float* Vn = Vs + ((c + 1) & 1) * WVSTAGE;
+        const float* Rn = Rs + ((c + 1) & 1) * WRBUF;
+        const bool xf = c + 1 < nch, pre = c + 2 < nch;
+        if (pre) raw_load(c + 2);
+        f32x4 aq[2];
+        aq[0] = *(const f32x4*)(Vc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j + 1 < 4) aq[(j + 1) & 1] = *(const f32x4*)(Vc + (j + 1) * WTILES * WVSTR);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) bq[(j + PF) % RING][n] = buf_load4(wsr, wvo, wso + (j + PF) * 2048 + n * 1024);
+            // the input transform of the NEXT chunk rides along with this chunk's MFMAs
+            if (xf) {
+                if (j == 0) xf_read(Rn);
+                if (j == 1) xf_rows();
+                if (j == 2) xf_write(Vn);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j & 1][s], bq[j % RING][n][s], acc[j][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wso += 8192;
+        if (pre) raw_store(Rs + (c & 1) * WRBUF);
+        __syncthreads();
+    }
+
+    // ---- epilogue: row reduction P = M A, exchange through LDS, Y = A^T P -----------------------------------------
+    // P[b=0] = M0 + M1 + M2 ; P[b=1] = M1 - M2 - M3.  LDS P[mh][i][b][tile 32][co 64]
+    {
+        float* Pw = smem + ((mh * 4 + wi) * 2) * (32 * 64);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int trow = (r & 3) + 8 * (r >> 2) + 4 * lh;      // tile inside the M-tile (C layout row)
+                const float p0 = acc[0][n][r] + acc[1][n][r] + acc[2][n][r];
+                const float p1 = acc[1][n][r] - acc[2][n][r] - acc[3][n][r];
+                Pw[trow * 64 + n * 32 + li] = p0;
+                Pw[32 * 64 + trow * 64 + n * 32 + li] = p1;
+            }
+    }
+    __syncthreads();
+    {
+        const int co = ct * 64 + lane;
+        const float bias = a.bias[co];
+        const float* Pm = smem + (mh * 4 * 2) * (32 * 64);
+        const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+#pragma unroll 2
+        for (int t = 0; t < 8; ++t) {
+            const int tl = wi * 8 + t;                 // tile inside the M-tile
+            const int tile = mh * 32 + tl;
+            const int oy = ty0 + 2 * (tile >> 4), ox = tx0 + 2 * (tile & 15);
+            if (oy >= a.H || ox >= a.W) continue;
+            float P[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) P[i][b] = Pm[((i * 2 + b) * 32 + tl) * 64 + lane];
+            float y[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                y[0][b] = P[0][b] + P[1][b] + P[2][b] + bias;
+                y[1][b] = P[1][b] - P[2][b] - P[3][b] + bias;
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) y[i][b] = fmaxf(y[i][b], 0.f);
+            }
+            const bool row1 = oy + 1 < a.H, col1 = ox + 1 < a.W;
+            if (a.pool_out) {
+                float v = y[0][0];
+                if (col1) v = fmaxf(v, y[0][1]);
+                if (row1) {
+                    v = fmaxf(v, y[1][0]);
+                    if (col1) v = fmaxf(v, y[1][1]);
+                }
+                a.out[(((size_t)img * Hp + (oy >> 1)) * Wp + (ox >> 1)) * a.cout + co] = v;
+            } else {
+                float* o = a.out + (((size_t)img * a.H + oy) * a.W + ox) * a.cout + co;
+                o[0] = y[0][0];
+                if (col1) o[a.cout] = y[0][1];
+                if (row1) {
+                    o[(size_t)a.W * a.cout] = y[1][0];
+                    if (col1) o[(size_t)a.W * a.cout + a.cout] = y[1][1];
+                }
+            }
+        }
+    }
+}
+
+int launch_pack_wino(const float* w, float* p, int cin, int cout, hipStream_t s) {
+    if (cin % WKC || cout % 64) { set_error("pack_wino: cin %% 8 or cout %% 64 != 0 (%d, %d)", cin, cout); return -1; }
+    const size_t total = (size_t)cin * cout * 16;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(blocks), dim3(256), 0, s, w, p, cin, cout);
+    return check_launch("pack_wino");
+}
+
+int launch_conv3x3_wino(const ConvArgs& a0, int src_mode, hipStream_t s) {
+    ConvArgs a = a0;
+    if (a.cin % WKC || a.cin < WKC) { set_error("conv3x3_wino: cin %d not a multiple of 8", a.cin); return -1; }
+    if (a.cout % 64) { set_error("conv3x3_wino: cout %d not a multiple of 64", a.cout); return -1; }
+    if (a.H < 2 || a.W < 2 || a.n < 1) { set_error("conv3x3_wino: H, W must be >= 2, got %dx%d", a.H, a.W); return -1; }
+    if ((size_t)a.Hs * a.Ws * a.cin * 4 >= 0x7fffffffULL) { set_error("conv3x3_wino: per-image source tensor must stay below 2 GiB"); return -1; }
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + 7) / 8;
+    const long long blocks = (long long)a.tiles_x * a.tiles_y * (a.cout / 64) * a.n;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv3x3_wino: bad grid %lld", blocks); return -1; }
+    a.xcd_order = 1;
+    if (src_mode == SRC_DIRECT) {
+        if (a.Hs != a.H || a.Ws != a.W) { set_error("conv3x3_wino: direct mode needs Hs==H, Ws==W"); return -1; }
+        hipLaunchKernelGGL(conv3x3_wino_kernel<SRC_DIRECT>, dim3((unsigned)blocks), dim3(512), 0, s, a);
+    } else if (src_mode == SRC_UP2X) {
+        if (a.H != 2 * a.Hs || a.W != 2 * a.Ws) { set_error("conv3x3_wino: up2x mode needs H==2Hs, W==2Ws"); return -1; }
+        hipLaunchKernelGGL(conv3x3_wino_kernel<SRC_UP2X>, dim3((unsigned)blocks), dim3(512), 0, s, a);
+    } else {
+        set_error("conv3x3_wino: unsupported src_mode %d", src_mode);
+        return -1;
+    }
+    return check_launch("conv3x3_wino");
+}
+
+}  // namespace adain

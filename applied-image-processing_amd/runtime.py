@@ -50,6 +50,9 @@ SIGNATURES = {
     "adain_conv3x3_packed_floats": (_c_size_t, [_c_int, _c_int]),
     "adain_conv3x3_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
     "adain_conv3x3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 11 + [_c_void_p]),
+    "adain_conv3x3_wino_packed_floats": (_c_size_t, [_c_int, _c_int]),
+    "adain_conv3x3_wino_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
+    "adain_conv3x3_wino": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 10 + [_c_void_p]),
 }
 
 _lib = None
@@ -367,4 +370,26 @@ def conv3x3(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, pool_o
     with torch.cuda.device(x.device):
         _check(lib().adain_conv3x3(x.data_ptr(), out.data_ptr(), packed_w.data_ptr(), bias.data_ptr(), n, h, w, hs, ws_, cin, cout,
                                    src_mode, int(relu), int(pool_out), int(variant), _stream()), "adain_conv3x3")
+    return out
+
+
+def conv3x3_wino_pack(w_oihw):
+    w = _dev(w_oihw, "weight")
+    cout, cin = w.shape[:2]
+    packed = torch.empty(lib().adain_conv3x3_wino_packed_floats(cin, cout), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _check(lib().adain_conv3x3_wino_pack(w.data_ptr(), packed.data_ptr(), cin, cout, _stream()), "adain_conv3x3_wino_pack")
+    return packed
+
+
+def conv3x3_wino(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, pool_out=False):
+    """Winograd F(2x2,3x3) form of conv3x3 (weights packed by conv3x3_wino_pack)."""
+    x = _dev(x_nhwc, "x")
+    n, hs, ws_, cin = x.shape
+    h, w = (2 * hs, 2 * ws_) if src_mode == SRC_UP2X else (hs, ws_)
+    oh, ow = ((h + 1) // 2, (w + 1) // 2) if pool_out else (h, w)
+    out = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().adain_conv3x3_wino(x.data_ptr(), out.data_ptr(), packed_w.data_ptr(), bias.data_ptr(), n, h, w, hs, ws_, cin, cout,
+                                        src_mode, int(relu), int(pool_out), _stream()), "adain_conv3x3_wino")
     return out

@@ -37,6 +37,7 @@ import applied_image_processing_amd.sharding as sh
 import applied_image_processing_amd.synth as synth
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)"
+WINOGRAD = os.environ.get("ADAIN_WINOGRAD", "1") != "0"      # the C library's default; ADAIN_WINOGRAD=0 = direct implicit GEMM
 WORKLOADS = {
     2: "configs[1]: {h}x{w} AdaIN forward (style_transfer_simple), batch={b} per GPU, style {hs}x{ws} re-encoded every step, alpha=0.5",
     3: "configs[2]: {h}x{w} depth-aware AdaIN (style_transfer, proximity-map blend), batch={b} per GPU, style {hs}x{ws} re-encoded every step",
@@ -212,8 +213,12 @@ def measure_roofline(step, reps):
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
         "traffic": load_pmc_traffic(f"config{step.config}_batch{step.batch}"),
-        "kernel": f"conv3x3_mfma_kernel ({len(flops)} launches/step)", "avg_launch_ms": round(avg_ms, 4),
-        "flop_per_launch_avg": sum(flops) / len(flops),
+        "kernel": ("conv3x3_wino_kernel" if WINOGRAD else "conv3x3_mfma_kernel") + f" ({len(flops)} launches/step)",
+        "avg_launch_ms": round(avg_ms, 4), "flop_per_launch_avg": sum(flops) / len(flops),
+        # `achieved` counts the ALGORITHMIC flops of the direct 3x3 convolution.  The Winograd F(2x2,3x3)
+        # kernel executes 16/36 of those multiplies on the matrix pipe, which is how `frac` can exceed 1.
+        "executed_mfma_tflops": round(achieved * (16.0 / 36.0 if WINOGRAD else 1.0), 2),
+        "executed_mfma_frac": round(achieved * (16.0 / 36.0 if WINOGRAD else 1.0) / PEAK_FP32_MFMA_TFLOPS, 4),
         "algorithmic_bytes_per_launch_avg": sum(step.conv3x3_algorithmic_bytes()) / len(flops),
     }, layers
 

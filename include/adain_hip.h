@@ -130,6 +130,15 @@ int adain_conv3x3(const float* in_nhwc, float* out_nhwc, const float* packed_w, 
                   int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out, int variant,
                   adain_stream_t stream);
 
+/* Winograd F(2x2,3x3) form of the same layer (2.25x fewer multiplies; fp32 rounding error ~2x the direct form's),
+ * used by adain_encode / adain_decode for the cin >= 128 layers.  Takes its own packing (16 floats per
+ * (cin, cout) pair).  src_mode DIRECT or UP2X; cin % 8 == 0, cout % 64 == 0. */
+size_t adain_conv3x3_wino_packed_floats(int cin, int cout);
+int adain_conv3x3_wino_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
+int adain_conv3x3_wino(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,
+                       int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out,
+                       adain_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

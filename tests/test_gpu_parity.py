@@ -105,6 +105,25 @@ def test_conv3x3_tile_variants_and_fused_output_pool(rt, variant, shape):
             rt.conv3x3(xg, packed, b.cuda(), cout, rt.SRC_DIRECT, relu=True, pool_out=True, variant=variant)
 
 
+@pytest.mark.parametrize("mode", ["direct", "up"])
+@pytest.mark.parametrize("shape", [(1, 128, 128, 16, 32), (2, 128, 64, 9, 37), (1, 256, 128, 21, 70), (1, 512, 256, 5, 6), (1, 64, 64, 8, 8)])
+def test_conv3x3_winograd_vs_oracle(rt, mode, shape):
+    """Winograd F(2x2,3x3) kernel against torch's direct convolution (same tolerance as the direct kernel)."""
+    n, cin, cout, hs, ws = shape
+    x = T(synth.uniform_sym(400 + cin, (n, cin, hs, ws), 1.0))
+    w = T(synth.uniform_sym(500 + cout, (cout, cin, 3, 3), (6.0 / (9 * cin)) ** 0.5))
+    b = T(synth.uniform_sym(600 + cout, (cout,), 0.1))
+    src = F.interpolate(x, scale_factor=2, mode="nearest") if mode == "up" else x
+    pre = F.conv2d(F.pad(src, (1, 1, 1, 1), mode="reflect"), w, b)
+    xg = x.cuda().permute(0, 2, 3, 1).contiguous()
+    packed = rt.conv3x3_wino_pack(w.cuda())
+    m = rt.SRC_UP2X if mode == "up" else rt.SRC_DIRECT
+    close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True).permute(0, 3, 1, 2), F.relu(pre))
+    close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=False).permute(0, 3, 1, 2), pre)
+    close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True, pool_out=True).permute(0, 3, 1, 2),
+          F.max_pool2d(F.relu(pre), 2, 2, 0, ceil_mode=True))
+
+
 def test_conv3x3_rejects_bad_shapes(rt):
     x = torch.zeros(1, 4, 4, 24, device="cuda")
     with pytest.raises(rt.AdainHipError):

@@ -54,12 +54,21 @@ def main():
         w = torch.from_numpy(synth.uniform_sym(2, (cout, cin, 3, 3), (6.0 / (9 * cin)) ** 0.5)).to(dev)
         b = torch.zeros(cout, device=dev)
         packed = rt.conv3x3_pack(w)
+        wino = rt.conv3x3_wino_pack(w) if cin % 8 == 0 and mode != rt.SRC_POOL2 else None
+
+        def run(v):
+            if v == 20:      # Winograd F(2x2,3x3)
+                if wino is None:
+                    raise rt.AdainHipError("no winograd form")
+                return rt.conv3x3_wino(x, wino, b, cout, mode, True, pool)
+            return rt.conv3x3(x, packed, b, cout, mode, True, pool, v)
+
         flops = 2.0 * h * h * cin * cout * 9
         times = {v: [] for v in variants}
         ok = {}
         for v in variants:
             try:
-                rt.conv3x3(x, packed, b, cout, mode, True, pool, v)
+                run(v)
                 ok[v] = True
             except rt.AdainHipError:
                 ok[v] = False
@@ -71,7 +80,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.burst):          # back-to-back launches: steady-state clocks, no idle gaps
-                    rt.conv3x3(x, packed, b, cout, mode, True, pool, v)
+                    run(v)
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / args.burst)
