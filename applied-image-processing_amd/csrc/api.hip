@@ -78,11 +78,16 @@ static bool use_winograd() {
     return on;
 }
 
+static int wino_mh() {
+    static const int mh = getenv("ADAIN_WINO_MH") ? atoi(getenv("ADAIN_WINO_MH")) : 2;
+    return mh;
+}
+
 static int launch_layer(ConvArgs& a, const float* packed, const Offsets& f, int i, int src, hipStream_t s) {
     a.bias = packed + f.b[i];
     if (use_winograd() && src != SRC_POOL2) {
         a.wpk = packed + f.ww[i];
-        return launch_conv3x3_wino(a, src, s);
+        return launch_conv3x3_wino(a, src, wino_mh(), s);
     }
     a.wpk = packed + f.w[i];
     return launch_conv3x3(a, src, -1, s);
@@ -335,12 +340,12 @@ int adain_conv3x3_wino_pack(const float* w, float* packed, int cin, int cout, ad
 }
 
 int adain_conv3x3_wino(const float* in, float* out, const float* packed_w, const float* bias, int n, int h, int w, int hs, int ws,
-                       int cin, int cout, int src_mode, int relu, int pool_out, adain_stream_t stream) {
+                       int cin, int cout, int src_mode, int relu, int pool_out, int mh, adain_stream_t stream) {
     if (!in || !out || !packed_w || !bias) { set_error("conv3x3_wino: null pointer"); return ADAIN_EINVAL; }
     ConvArgs a{};
     a.in = in; a.out = out; a.wpk = packed_w; a.bias = bias;
     a.n = n; a.H = h; a.W = w; a.Hs = hs; a.Ws = ws; a.cin = cin; a.cout = cout; a.relu = relu; a.pool_out = pool_out ? 1 : 0;
-    return launch_conv3x3_wino(a, src_mode, (hipStream_t)stream);
+    return launch_conv3x3_wino(a, src_mode, mh, (hipStream_t)stream);
 }
 
 }  // extern "C"

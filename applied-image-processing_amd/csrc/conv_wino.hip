@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvArgs a) {
         float* Vn = Vs + ((c + 1) & 1) * WVSTAGE;
         const float* Rn = Rs + ((c + 1) & 1) * WRBUF;
         const bool xf = c + 1 < nch, pre = c + 2 < nch;
-        if (pre) raw_load(c + 2);
+        if (pre && EXPER != 1) raw_load(c + 2);      // EXPER: timing-only builds (wrong results), tools/tune_conv.py only
         f32x4 aq[2];
         aq[0] = *(const f32x4*)(Vc);
 #pragma unroll
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvArgs a) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) bq[(j + PF) % RING][n] = buf_load4(wsr, wvo, wso + (j + PF) * 2048 + n * 1024);
             // the input transform of the NEXT chunk rides along with this chunk's MFMAs
-            if (xf) {
+            if (xf && EXPER != 2) {
                 if (j == 0) xf_read(Rn);
                 if (j == 1) xf_rows();
                 if (j == 2) xf_write(Vn);
@@ -194,6 +194,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvArgs a) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j & 1][s], bq[j % RING][n][s], acc[j][n], 0, 0, 0);
+            // issue order of the step: loads first (next A fragment, weight prefetch, the transform's LDS reads), then
+            // the 8 MFMAs with the transform's VALU / LDS-write work dealt out between them, so that this wave's
+            // non-matrix instructions issue under its own MFMAs instead of in front of them
+            __builtin_amdgcn_sched_group_barrier(0x100, j == 0 ? 9 : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                if (j == 2 && (m & 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         wso += 8192;

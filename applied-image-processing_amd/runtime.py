@@ -52,7 +52,7 @@ SIGNATURES = {
     "adain_conv3x3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 11 + [_c_void_p]),
     "adain_conv3x3_wino_packed_floats": (_c_size_t, [_c_int, _c_int]),
     "adain_conv3x3_wino_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
-    "adain_conv3x3_wino": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 10 + [_c_void_p]),
+    "adain_conv3x3_wino": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 11 + [_c_void_p]),
 }
 
 _lib = None
@@ -382,7 +382,7 @@ def conv3x3_wino_pack(w_oihw):
     return packed
 
 
-def conv3x3_wino(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, pool_out=False):
+def conv3x3_wino(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, pool_out=False, m_tiles=2):
     """Winograd F(2x2,3x3) form of conv3x3 (weights packed by conv3x3_wino_pack)."""
     x = _dev(x_nhwc, "x")
     n, hs, ws_, cin = x.shape
@@ -391,5 +391,5 @@ def conv3x3_wino(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, p
     out = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _check(lib().adain_conv3x3_wino(x.data_ptr(), out.data_ptr(), packed_w.data_ptr(), bias.data_ptr(), n, h, w, hs, ws_, cin, cout,
-                                        src_mode, int(relu), int(pool_out), _stream()), "adain_conv3x3_wino")
+                                        src_mode, int(relu), int(pool_out), int(m_tiles), _stream()), "adain_conv3x3_wino")
     return out

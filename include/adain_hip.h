@@ -137,6 +137,7 @@ size_t adain_conv3x3_wino_packed_floats(int cin, int cout);
 int adain_conv3x3_wino_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
 int adain_conv3x3_wino(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,
                        int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out,
+                       int m_tiles /* 32-tile M-tiles per workgroup: 2 (8 waves, 8x32 px) or 1 (4 waves, 4x32 px) */,
                        adain_stream_t stream);
 
 #ifdef __cplusplus

@@ -105,9 +105,10 @@ def test_conv3x3_tile_variants_and_fused_output_pool(rt, variant, shape):
             rt.conv3x3(xg, packed, b.cuda(), cout, rt.SRC_DIRECT, relu=True, pool_out=True, variant=variant)
 
 
+@pytest.mark.parametrize("m_tiles", [2, 1])
 @pytest.mark.parametrize("mode", ["direct", "up"])
 @pytest.mark.parametrize("shape", [(1, 128, 128, 16, 32), (2, 128, 64, 9, 37), (1, 256, 128, 21, 70), (1, 512, 256, 5, 6), (1, 64, 64, 8, 8)])
-def test_conv3x3_winograd_vs_oracle(rt, mode, shape):
+def test_conv3x3_winograd_vs_oracle(rt, mode, shape, m_tiles):
     """Winograd F(2x2,3x3) kernel against torch's direct convolution (same tolerance as the direct kernel)."""
     n, cin, cout, hs, ws = shape
     x = T(synth.uniform_sym(400 + cin, (n, cin, hs, ws), 1.0))
@@ -118,9 +119,9 @@ def test_conv3x3_winograd_vs_oracle(rt, mode, shape):
     xg = x.cuda().permute(0, 2, 3, 1).contiguous()
     packed = rt.conv3x3_wino_pack(w.cuda())
     m = rt.SRC_UP2X if mode == "up" else rt.SRC_DIRECT
-    close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True).permute(0, 3, 1, 2), F.relu(pre))
-    close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=False).permute(0, 3, 1, 2), pre)
-    close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True, pool_out=True).permute(0, 3, 1, 2),
+    close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True, m_tiles=m_tiles).permute(0, 3, 1, 2), F.relu(pre))
+    close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=False, m_tiles=m_tiles).permute(0, 3, 1, 2), pre)
+    close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True, pool_out=True, m_tiles=m_tiles).permute(0, 3, 1, 2),
           F.max_pool2d(F.relu(pre), 2, 2, 0, ceil_mode=True))
 
 
