@@ -22,6 +22,8 @@
 //     (all 128 KiB), then every lane owns one channel and finishes Y = A^T P for 8 tiles: bias, ReLU,
 //     optional 2x2 max-pool of the output (the 4 outputs of a Winograd tile ARE one pool window), stores of
 //     256 contiguous bytes per pixel.
+#include <type_traits>
+
 #include "common.h"
 #include "device_utils.h"
 
@@ -29,12 +31,23 @@ namespace adain {
 
 constexpr int WKC = 8;                 // channels per chunk
 constexpr int WVSTR = 12;              // floats per V row (8 channels + 4 pad)
-constexpr int WTILES = 64;             // Winograd tiles per block
-constexpr int WVSTAGE = 16 * WTILES * WVSTR;          // 12288 floats
-constexpr int WHALO_W = 34, WHALO = 10 * WHALO_W;     // raw halo pixels
-constexpr int WRBUF = WHALO * WVSTR;                  // 4080 floats
-constexpr int WLDS = 32768;                           // floats (128 KiB): max(2 V + 2 raw, P exchange)
-static_assert(2 * WVSTAGE + 2 * WRBUF <= WLDS, "LDS layout");
+constexpr int WHALO_W = 34;            // raw halo width (32 + 2)
+
+// geometry by MH = number of 32-tile M-tiles per block (MH*4 waves):
+//   MH = 2: 8 x 32 output pixels, 8 waves, 128 KiB LDS, one block per CU
+//   MH = 1: 4 x 32 output pixels, 4 waves, 69 KiB LDS, two independent blocks per CU (their barriers overlap):
+//           5-10 % faster on every config-2 layer, the default
+template <int MH>
+struct WinoGeo {
+    static constexpr int TILES = 32 * MH;
+    static constexpr int VSTAGE = 16 * TILES * WVSTR;
+    static constexpr int HALO = (4 * MH + 2) * WHALO_W;
+    static constexpr int RBUF = HALO * WVSTR;
+    static constexpr int PEX = MH * 4 * 2 * 32 * 64;
+    static constexpr int LDS = (2 * VSTAGE + 2 * RBUF) > PEX ? (2 * VSTAGE + 2 * RBUF) : PEX;
+    static constexpr int NTHR = MH * 256;
+    static constexpr int RITEMS = (HALO * 2 + NTHR - 1) / NTHR;
+};
 
 // OIHW [cout][cin][3][3] -> U = G g G^T packed as [cout/64][i 4][cin/8][j 4][n 2][lane 64][s 4]:
 //   value = U[xi = 4 i + j][cout = 64 ct + 32 n + (lane & 31)][cin = 8 chunk + 4 (lane >> 5) + s]
@@ -62,16 +75,20 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[WLDS];
+// EXPER != 0: timing-only builds for tools/tune_conv.py (1: no raw prefetch loads, 2: no input transform; wrong results)
+template <int MODE, int MH, int EXPER = 0, bool SCHED = true>
+__global__ __launch_bounds__(MH * 256, 2) void conv3x3_wino_kernel(ConvArgs a) {
+    using Geo = WinoGeo<MH>;
+    constexpr int WTILES = Geo::TILES, WVSTAGE = Geo::VSTAGE, WHALO = Geo::HALO, WRBUF = Geo::RBUF, NTHR = Geo::NTHR;
+    constexpr int RITEMS = Geo::RITEMS;
+    __shared__ __attribute__((aligned(16))) float smem[Geo::LDS];
     float* const Vs = smem;                      // 2 stages
     float* const Rs = smem + 2 * WVSTAGE;        // 2 raw halo buffers
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mh = wave >> 2, wi = wave & 3;
+    const int mh = wave >> 2, wi = wave & 3;     // M-tile, transform row
     const int li = lane & 31, lh = lane >> 5;
 
     // block -> (pixel tile, channel tile, image), XCD-aware order as in conv.hip
@@ -82,38 +99,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvArgs a) {
     const int ct = lid % nct; lid /= nct;
     const int pt = lid % tiles;
     const int img = lid / tiles;
-    const int tx0 = (pt % a.tiles_x) * 32, ty0 = (pt / a.tiles_x) * 8;
+    const int tx0 = (pt % a.tiles_x) * 32, ty0 = (pt / a.tiles_x) * (4 * MH);
     const int nch = a.cin / WKC;
 
     const rsrc_t src = make_rsrc(a.in + (size_t)img * a.Hs * a.Ws * a.cin, (unsigned)a.Hs * a.Ws * a.cin * 4u);
     const rsrc_t wsr = make_rsrc(a.wpk, (unsigned)a.cin * a.cout * 64u);
 
-    // ---- raw halo staging: 680 items (pixel, quad) over 512 threads ------------------------------------------
-    int roff[2];
+    // ---- raw halo staging: HALO*2 items (pixel, quad) over the block's threads ----------------------------------
+    int roff[RITEMS];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int idx = tid + k * 512;
+    for (int k = 0; k < RITEMS; ++k) {
+        const int idx = tid + k * NTHR;
         const int hp = min(idx >> 1, WHALO - 1), q = idx & 1;
         const int hy = hp / WHALO_W, hx = hp - hy * WHALO_W;
         int y = reflect1(ty0 + hy - 1, a.H), x = reflect1(tx0 + hx - 1, a.W);
         if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
         roff[k] = ((y * a.Ws + x) * a.cin + q * 4) * 4;
     }
-    f32x4 rawreg[2];
+    f32x4 rawreg[RITEMS];
     auto raw_load = [&](int chunk) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) rawreg[k] = buf_load4(src, roff[k], chunk * WKC * 4);
+        for (int k = 0; k < RITEMS; ++k) rawreg[k] = buf_load4(src, roff[k], chunk * WKC * 4);
     };
     auto raw_store = [&](float* buf) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int idx = tid + k * 512;
+        for (int k = 0; k < RITEMS; ++k) {
+            const int idx = tid + k * NTHR;
             if (idx < WHALO * 2) *(f32x4*)(buf + (idx >> 1) * WVSTR + (idx & 1) * 4) = rawreg[k];
         }
     };
 
     // ---- input transform unit of this thread: column tc of the patch of tile ut, channel quad uq ----------------
-    const int tc = tid >> 7, ut = (tid & 127) >> 1, uq = tid & 1;
+    // (tc is the same for a whole wave: readfirstlane makes that provable, so its branches below are scalar)
+    const int tc = __builtin_amdgcn_readfirstlane(tid / (NTHR / 4)), ut = (tid % (NTHR / 4)) >> 1, uq = tid & 1;
     const int u_base = ((2 * (ut >> 4)) * WHALO_W + 2 * (ut & 15)) * WVSTR + uq * 4;     // patch origin in the raw buffer
     const int colA = tc == 0 ? 0 : 1, colB = tc == 3 ? 3 : 2;
     const int v_base = (tc * WTILES + ut) * WVSTR + uq * 4;                             // V[xi = 4 i + tc][ut][uq*4]
@@ -175,38 +193,58 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(ConvArgs a) {
         float* Vn = Vs + ((c + 1) & 1) * WVSTAGE;
         const float* Rn = Rs + ((c + 1) & 1) * WRBUF;
         const bool xf = c + 1 < nch, pre = c + 2 < nch;
-        if (pre && EXPER != 1) raw_load(c + 2);      // EXPER: timing-only builds (wrong results), tools/tune_conv.py only
+        if (pre && EXPER != 1) raw_load(c + 2);
         f32x4 aq[2];
         aq[0] = *(const f32x4*)(Vc);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j + 1 < 4) aq[(j + 1) & 1] = *(const f32x4*)(Vc + (j + 1) * WTILES * WVSTR);
+        auto step = [&](auto JJ) {
+            constexpr int j = decltype(JJ)::value;
+            if constexpr (j + 1 < 4) aq[(j + 1) & 1] = *(const f32x4*)(Vc + (j + 1) * WTILES * WVSTR);
 #pragma unroll
             for (int n = 0; n < 2; ++n) bq[(j + PF) % RING][n] = buf_load4(wsr, wvo, wso + (j + PF) * 2048 + n * 1024);
             // the input transform of the NEXT chunk rides along with this chunk's MFMAs
             if (xf && EXPER != 2) {
-                if (j == 0) xf_read(Rn);
-                if (j == 1) xf_rows();
-                if (j == 2) xf_write(Vn);
+                if constexpr (j == 0) xf_read(Rn);
+                if constexpr (j == 1) xf_rows();
+                if constexpr (j == 2) xf_write(Vn);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j & 1][s], bq[j % RING][n][s], acc[j][n], 0, 0, 0);
-            // issue order of the step: loads first (next A fragment, weight prefetch, the transform's LDS reads), then
-            // the 8 MFMAs with the transform's VALU / LDS-write work dealt out between them, so that this wave's
-            // non-matrix instructions issue under its own MFMAs instead of in front of them
-            __builtin_amdgcn_sched_group_barrier(0x100, j == 0 ? 9 : 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
+            if constexpr (SCHED) {
+                // issue order of the step: loads first (next A fragment, weight prefetch, the transform's LDS reads),
+                // then the 8 MFMAs with the transform's VALU / LDS-write work dealt out between them, so that this
+                // wave's non-matrix instructions issue under its own MFMAs instead of in front of them
+                __builtin_amdgcn_sched_group_barrier(0x100, j == 0 ? 9 : (j == 3 ? 0 : 1), 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                if (j == 2 && (m & 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                if constexpr (j == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                if constexpr (j == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                if constexpr (j == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                if constexpr (j == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
         wso += 8192;
         if (pre) raw_store(Rs + (c & 1) * WRBUF);
         __syncthreads();
@@ -286,26 +324,39 @@ int launch_pack_wino(const float* w, float* p, int cin, int cout, hipStream_t s)
     return check_launch("pack_wino");
 }
 
-int launch_conv3x3_wino(const ConvArgs& a0, int src_mode, hipStream_t s) {
+int launch_conv3x3_wino(const ConvArgs& a0, int src_mode, int mh, hipStream_t s) {
     ConvArgs a = a0;
     if (a.cin % WKC || a.cin < WKC) { set_error("conv3x3_wino: cin %d not a multiple of 8", a.cin); return -1; }
     if (a.cout % 64) { set_error("conv3x3_wino: cout %d not a multiple of 64", a.cout); return -1; }
     if (a.H < 2 || a.W < 2 || a.n < 1) { set_error("conv3x3_wino: H, W must be >= 2, got %dx%d", a.H, a.W); return -1; }
     if ((size_t)a.Hs * a.Ws * a.cin * 4 >= 0x7fffffffULL) { set_error("conv3x3_wino: per-image source tensor must stay below 2 GiB"); return -1; }
-    a.tiles_x = (a.W + 31) / 32;
-    a.tiles_y = (a.H + 7) / 8;
-    const long long blocks = (long long)a.tiles_x * a.tiles_y * (a.cout / 64) * a.n;
-    if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv3x3_wino: bad grid %lld", blocks); return -1; }
-    a.xcd_order = 1;
     if (src_mode == SRC_DIRECT) {
         if (a.Hs != a.H || a.Ws != a.W) { set_error("conv3x3_wino: direct mode needs Hs==H, Ws==W"); return -1; }
-        hipLaunchKernelGGL(conv3x3_wino_kernel<SRC_DIRECT>, dim3((unsigned)blocks), dim3(512), 0, s, a);
     } else if (src_mode == SRC_UP2X) {
         if (a.H != 2 * a.Hs || a.W != 2 * a.Ws) { set_error("conv3x3_wino: up2x mode needs H==2Hs, W==2Ws"); return -1; }
-        hipLaunchKernelGGL(conv3x3_wino_kernel<SRC_UP2X>, dim3((unsigned)blocks), dim3(512), 0, s, a);
     } else {
         set_error("conv3x3_wino: unsupported src_mode %d", src_mode);
         return -1;
+    }
+    const int geo = mh == 2 ? 2 : 1;
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + 4 * geo - 1) / (4 * geo);
+    const long long blocks = (long long)a.tiles_x * a.tiles_y * (a.cout / 64) * a.n;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv3x3_wino: bad grid %lld", blocks); return -1; }
+    a.xcd_order = 1;
+    const dim3 g((unsigned)blocks);
+    const bool up = src_mode == SRC_UP2X;
+    switch (mh) {
+        case 2:
+            if (up) hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_UP2X, 2>), g, dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_DIRECT, 2>), g, dim3(512), 0, s, a);
+            break;
+        case 101: hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_DIRECT, 1, 1>), g, dim3(256), 0, s, a); break;          // timing only
+        case 102: hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_DIRECT, 1, 2>), g, dim3(256), 0, s, a); break;          // timing only
+        case 103: hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_DIRECT, 1, 0, false>), g, dim3(256), 0, s, a); break;   // A/B: order not pinned
+        default:
+            if (up) hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_UP2X, 1>), g, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_DIRECT, 1>), g, dim3(256), 0, s, a);
     }
     return check_launch("conv3x3_wino");
 }
