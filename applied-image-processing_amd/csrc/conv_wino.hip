@@ -18,6 +18,11 @@
 //   * B operand: transformed weights U = G g G^T are packed on the device once per weight set into
 //     per-lane fragment order [cout/64][row i][chunk][j][n][lane][4] and streamed straight into VGPRs
 //     (the two M-tile waves of a row share them through L1);
+//   Measured while tuning (tools/tune_conv.py, 256->256 at 256x256): 8 waves / one block per CU 228 TF/s (algorithmic),
+//   4 waves / two blocks per CU 237; without the input transform (timing-only build) 281, i.e. the fused transform
+//   costs ~19 % (14 % its LDS reads + adds, 3-5 % its V stores); fetching the patches straight from global memory
+//   instead of the raw-halo LDS image was 3 % SLOWER; pinning the issue order, scalar instead of packed adds and
+//   reading all A fragments at chunk start are each within +-1 %.
 //   * epilogue: each wave reduces its row (P = M A, two partial matrices), the 4 rows meet in LDS
 //     (all 128 KiB), then every lane owns one channel and finishes Y = A^T P for 8 tiles: bias, ReLU,
 //     optional 2x2 max-pool of the output (the 4 outputs of a Winograd tile ARE one pool window), stores of
@@ -75,8 +80,7 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-// EXPER != 0: timing-only builds for tools/tune_conv.py (1: no raw prefetch loads, 2: no input transform; wrong results)
-template <int MODE, int MH, int EXPER = 0, bool SCHED = true>
+template <int MODE, int MH>
 __global__ __launch_bounds__(MH * 256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     using Geo = WinoGeo<MH>;
     constexpr int WTILES = Geo::TILES, WVSTAGE = Geo::VSTAGE, WHALO = Geo::HALO, WRBUF = Geo::RBUF, NTHR = Geo::NTHR;
@@ -193,16 +197,17 @@ __global__ __launch_bounds__(MH * 256, 2) void conv3x3_wino_kernel(ConvArgs a) {
         float* Vn = Vs + ((c + 1) & 1) * WVSTAGE;
         const float* Rn = Rs + ((c + 1) & 1) * WRBUF;
         const bool xf = c + 1 < nch, pre = c + 2 < nch;
-        if (pre && EXPER != 1) raw_load(c + 2);
-        f32x4 aq[2];
-        aq[0] = *(const f32x4*)(Vc);
+        if (pre) raw_load(c + 2);
+        // all four A fragments of the chunk up front: their LDS reads must not queue behind the transform's LDS traffic
+        f32x4 aq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aq[j] = *(const f32x4*)(Vc + j * WTILES * WVSTR);
         auto step = [&](auto JJ) {
             constexpr int j = decltype(JJ)::value;
-            if constexpr (j + 1 < 4) aq[(j + 1) & 1] = *(const f32x4*)(Vc + (j + 1) * WTILES * WVSTR);
 #pragma unroll
             for (int n = 0; n < 2; ++n) bq[(j + PF) % RING][n] = buf_load4(wsr, wvo, wso + (j + PF) * 2048 + n * 1024);
             // the input transform of the NEXT chunk rides along with this chunk's MFMAs
-            if (xf && EXPER != 2) {
+            if (xf) {
                 if constexpr (j == 0) xf_read(Rn);
                 if constexpr (j == 1) xf_rows();
                 if constexpr (j == 2) xf_write(Vn);
@@ -211,33 +216,21 @@ __global__ __launch_bounds__(MH * 256, 2) void conv3x3_wino_kernel(ConvArgs a) {
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j & 1][s], bq[j % RING][n][s], acc[j][n], 0, 0, 0);
-            if constexpr (SCHED) {
+                    acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j][s], bq[j % RING][n][s], acc[j][n], 0, 0, 0);
+            {
                 // issue order of the step: loads first (next A fragment, weight prefetch, the transform's LDS reads),
                 // then the 8 MFMAs with the transform's VALU / LDS-write work dealt out between them, so that this
                 // wave's non-matrix instructions issue under its own MFMAs instead of in front of them
-                __builtin_amdgcn_sched_group_barrier(0x100, j == 0 ? 9 : (j == 3 ? 0 : 1), 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                if constexpr (j == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                if constexpr (j == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                if constexpr (j == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                if constexpr (j == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                // one MFMA, then one slice of the transform (step 0: a raw-patch LDS read; steps 1, 2: VALU adds; step 2
+                // also the V stores).  The chunk's first MFMA must only wait for its A fragment, not for the raw reads.
+#define WINO_SLOT(M)                                                                                      \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+                if constexpr (j == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  \
+                if constexpr (j == 1 || j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);        \
+                if constexpr (j == 2 && ((M) & 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                WINO_SLOT(0) WINO_SLOT(1) WINO_SLOT(2) WINO_SLOT(3) WINO_SLOT(4) WINO_SLOT(5) WINO_SLOT(6) WINO_SLOT(7)
+#undef WINO_SLOT
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -346,17 +339,12 @@ int launch_conv3x3_wino(const ConvArgs& a0, int src_mode, int mh, hipStream_t s)
     a.xcd_order = 1;
     const dim3 g((unsigned)blocks);
     const bool up = src_mode == SRC_UP2X;
-    switch (mh) {
-        case 2:
-            if (up) hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_UP2X, 2>), g, dim3(512), 0, s, a);
-            else hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_DIRECT, 2>), g, dim3(512), 0, s, a);
-            break;
-        case 101: hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_DIRECT, 1, 1>), g, dim3(256), 0, s, a); break;          // timing only
-        case 102: hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_DIRECT, 1, 2>), g, dim3(256), 0, s, a); break;          // timing only
-        case 103: hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_DIRECT, 1, 0, false>), g, dim3(256), 0, s, a); break;   // A/B: order not pinned
-        default:
-            if (up) hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_UP2X, 1>), g, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_DIRECT, 1>), g, dim3(256), 0, s, a);
+    if (mh == 2) {
+        if (up) hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_UP2X, 2>), g, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_DIRECT, 2>), g, dim3(512), 0, s, a);
+    } else {
+        if (up) hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_UP2X, 1>), g, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_DIRECT, 1>), g, dim3(256), 0, s, a);
     }
     return check_launch("conv3x3_wino");
 }
