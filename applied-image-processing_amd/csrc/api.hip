@@ -79,7 +79,7 @@ static bool use_winograd() {
 }
 
 static int wino_mh() {
-    static const int mh = getenv("ADAIN_WINO_MH") ? atoi(getenv("ADAIN_WINO_MH")) : 1;   // 1: two 4-wave blocks per CU (default)
+    static const int mh = getenv("ADAIN_WINO_MH") ? atoi(getenv("ADAIN_WINO_MH")) : 3;   // 3: register-resident A (default); 1, 2: LDS V image
     return mh;
 }
 

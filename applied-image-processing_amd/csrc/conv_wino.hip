@@ -309,6 +309,223 @@ __global__ __launch_bounds__(MH * 256, 2) void conv3x3_wino_kernel(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Second form: the transformed input never touches LDS.  Wave i (transform row i) needs, for its A operand, exactly
+// V[i][0..3] of tile `lane & 31` for the 4 channels `4 * (lane >> 5) ..`, and row i of B^T d B depends on only TWO
+// rows of the 4x4 patch (B^T row i has two non-zeros).  So every lane reads its 2 x 4 patch pixels (b128 each) from
+// the raw halo image, combines them (16 + 16 adds) and holds the four A fragments of the next chunk in registers:
+// no V image (48 KB), no V stores, no A-fragment reads, and the raw halo is staged 16 channels at a time, so the
+// workgroup barrier comes once per 64 MFMAs per wave instead of once per 32.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
+    constexpr int KR = 16;                  // channels per raw stage = 2 MFMA chunks of 8
+    constexpr int RSTR = KR + 4;            // floats per halo pixel (80 B: conflict-free b128 for 16 distinct tiles)
+    constexpr int HALO = 6 * WHALO_W;       // 6 x 34 halo of a 4 x 32 pixel tile
+    constexpr int RBUF = HALO * RSTR;       // 4080 floats
+    constexpr int PEX = 4 * 2 * 32 * 64;    // epilogue exchange (64 KiB) >= 2 raw buffers
+    constexpr int RITEMS = (HALO * 4 + 255) / 256;
+    static_assert(2 * RBUF <= PEX, "LDS layout");
+    __shared__ __attribute__((aligned(16))) float smem[PEX];
+    float* const Rs = smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wi = __builtin_amdgcn_readfirstlane(tid >> 6);      // transform row of this wave
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int nct = a.cout / 64;
+    int lid = blockIdx.x;
+    if (a.xcd_order && (gridDim.x & 7) == 0) lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
+    const int ct = lid % nct; lid /= nct;
+    const int pt = lid % tiles;
+    const int img = lid / tiles;
+    const int tx0 = (pt % a.tiles_x) * 32, ty0 = (pt / a.tiles_x) * 4;
+    const int nst = a.cin / KR;
+
+    const rsrc_t src = make_rsrc(a.in + (size_t)img * a.Hs * a.Ws * a.cin, (unsigned)a.Hs * a.Ws * a.cin * 4u);
+    const rsrc_t wsr = make_rsrc(a.wpk, (unsigned)a.cin * a.cout * 64u);
+
+    // ---- raw halo staging: HALO x 4 quads over 256 threads ---------------------------------------------------------
+    int roff[RITEMS];
+#pragma unroll
+    for (int k = 0; k < RITEMS; ++k) {
+        const int idx = tid + k * 256;
+        const int hp = min(idx >> 2, HALO - 1), q = idx & 3;
+        const int hy = hp / WHALO_W, hx = hp - hy * WHALO_W;
+        int y = reflect1(ty0 + hy - 1, a.H), x = reflect1(tx0 + hx - 1, a.W);
+        if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
+        roff[k] = ((y * a.Ws + x) * a.cin + q * 4) * 4;
+    }
+    f32x4 rawreg[RITEMS];
+    auto raw_load = [&](int stage) {
+#pragma unroll
+        for (int k = 0; k < RITEMS; ++k) rawreg[k] = buf_load4(src, roff[k], stage * KR * 4);
+    };
+    auto raw_store = [&](float* buf) {
+#pragma unroll
+        for (int k = 0; k < RITEMS; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < HALO * 4) *(f32x4*)(buf + (idx >> 2) * RSTR + (idx & 3) * 4) = rawreg[k];
+        }
+    };
+
+    // ---- this lane's share of the input transform ------------------------------------------------------------------
+    // patch of tile li starts at halo pixel (2 * (li >> 4), 2 * (li & 15)); rows (rA, rB) feed transform row wi:
+    //   wi 0: d0 - d2   wi 1: d1 + d2   wi 2: d2 - d1   wi 3: d1 - d3      then across columns: e0-e2, e1+e2, e2-e1, e1-e3
+    const int rA = wi == 0 ? 0 : 1, rB = wi == 3 ? 3 : 2;
+    const int p_base = ((2 * (li >> 4)) * WHALO_W + 2 * (li & 15)) * RSTR + 4 * lh;
+    const int pA = p_base + rA * WHALO_W * RSTR, pB = p_base + rB * WHALO_W * RSTR;
+    f32x4 dA[4], dB[4];
+    auto xf_read = [&](const float* rb) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            dA[c] = *(const f32x4*)(rb + pA + c * RSTR);
+            dB[c] = *(const f32x4*)(rb + pB + c * RSTR);
+        }
+    };
+    auto xf_make = [&](f32x4 (&out)[4]) {
+        f32x4 e[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (wi == 1) e[c] = dA[c] + dB[c];
+            else if (wi == 2) e[c] = dB[c] - dA[c];
+            else e[c] = dA[c] - dB[c];
+        }
+        out[0] = e[0] - e[2];
+        out[1] = e[1] + e[2];
+        out[2] = e[2] - e[1];
+        out[3] = e[1] - e[3];
+    };
+
+    // ---- weights ------------------------------------------------------------------------------------------------------
+    const int wvo = lane * 16;
+    const int nch = a.cin / WKC;
+    int wso = ((ct * 4 + wi) * nch) * 8192;
+    constexpr int PF = 3, RING = 4;
+    f32x4 bq[RING][2];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bq[p][n] = buf_load4(wsr, wvo, wso + p * 2048 + n * 1024);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
+
+    // one chunk of 8 channels: 4 steps of 8 MFMAs on `use`; meanwhile `make` is filled from `nsrc` (next chunk's raw)
+    auto chunk = [&](const f32x4 (&use)[4], f32x4 (&make)[4], const float* nsrc, bool do_xf) {
+        auto step = [&](auto JJ) {
+            constexpr int j = decltype(JJ)::value;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) bq[(j + PF) % RING][n] = buf_load4(wsr, wvo, wso + (j + PF) * 2048 + n * 1024);
+            if (do_xf) {
+                if constexpr (j == 0) xf_read(nsrc);
+                if constexpr (j == 2) xf_make(make);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(use[j][s], bq[j % RING][n][s], acc[j][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        wso += 8192;
+    };
+
+    // ---- prologue ---------------------------------------------------------------------------------------------------------
+    f32x4 aq0[4], aq1[4];
+    raw_load(0);
+    raw_store(Rs);
+    __syncthreads();
+    if (nst > 1) raw_load(1);
+    xf_read(Rs);
+    xf_make(aq0);
+
+    for (int s = 0; s < nst; ++s) {
+        const float* cur = Rs + (s & 1) * RBUF;
+        float* nxt = Rs + ((s + 1) & 1) * RBUF;
+        const bool more = s + 1 < nst;
+        chunk(aq0, aq1, cur + 8, true);                 // channels 0..7 of the stage; prepares channels 8..15
+        if (more) raw_store(nxt);                       // the next stage's halo (loaded one stage ago)
+        __syncthreads();
+        if (s + 2 < nst) raw_load(s + 2);
+        chunk(aq1, aq0, nxt, more);                     // channels 8..15; prepares the next stage's first chunk
+    }
+    __syncthreads();
+
+    // ---- epilogue: identical to conv3x3_wino_kernel<MODE, 1> ----------------------------------------------------------------
+    {
+        float* Pw = smem + (wi * 2) * (32 * 64);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int trow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float p0 = acc[0][n][r] + acc[1][n][r] + acc[2][n][r];
+                const float p1 = acc[1][n][r] - acc[2][n][r] - acc[3][n][r];
+                Pw[trow * 64 + n * 32 + li] = p0;
+                Pw[32 * 64 + trow * 64 + n * 32 + li] = p1;
+            }
+    }
+    __syncthreads();
+    {
+        const int co = ct * 64 + lane;
+        const float bias = a.bias[co];
+        const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+#pragma unroll 2
+        for (int t = 0; t < 8; ++t) {
+            const int tl = wi * 8 + t;
+            const int oy = ty0 + 2 * (tl >> 4), ox = tx0 + 2 * (tl & 15);
+            if (oy >= a.H || ox >= a.W) continue;
+            float P[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) P[i][b] = smem[((i * 2 + b) * 32 + tl) * 64 + lane];
+            float y[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                y[0][b] = P[0][b] + P[1][b] + P[2][b] + bias;
+                y[1][b] = P[1][b] - P[2][b] - P[3][b] + bias;
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) y[i][b] = fmaxf(y[i][b], 0.f);
+            }
+            const bool row1 = oy + 1 < a.H, col1 = ox + 1 < a.W;
+            if (a.pool_out) {
+                float v = y[0][0];
+                if (col1) v = fmaxf(v, y[0][1]);
+                if (row1) {
+                    v = fmaxf(v, y[1][0]);
+                    if (col1) v = fmaxf(v, y[1][1]);
+                }
+                a.out[(((size_t)img * Hp + (oy >> 1)) * Wp + (ox >> 1)) * a.cout + co] = v;
+            } else {
+                float* o = a.out + (((size_t)img * a.H + oy) * a.W + ox) * a.cout + co;
+                o[0] = y[0][0];
+                if (col1) o[a.cout] = y[0][1];
+                if (row1) {
+                    o[(size_t)a.W * a.cout] = y[1][0];
+                    if (col1) o[(size_t)a.W * a.cout + a.cout] = y[1][1];
+                }
+            }
+        }
+    }
+}
+
 int launch_pack_wino(const float* w, float* p, int cin, int cout, hipStream_t s) {
     if (cin % WKC || cout % 64) { set_error("pack_wino: cin %% 8 or cout %% 64 != 0 (%d, %d)", cin, cout); return -1; }
     const size_t total = (size_t)cin * cout * 16;
@@ -339,7 +556,10 @@ int launch_conv3x3_wino(const ConvArgs& a0, int src_mode, int mh, hipStream_t s)
     a.xcd_order = 1;
     const dim3 g((unsigned)blocks);
     const bool up = src_mode == SRC_UP2X;
-    if (mh == 2) {
+    if (mh == 3 && a.cin % 16 == 0) {
+        if (up) hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_UP2X>), g, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a);
+    } else if (mh == 2) {
         if (up) hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_UP2X, 2>), g, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((conv3x3_wino_kernel<SRC_DIRECT, 2>), g, dim3(512), 0, s, a);
     } else {

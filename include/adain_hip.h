@@ -137,7 +137,8 @@ size_t adain_conv3x3_wino_packed_floats(int cin, int cout);
 int adain_conv3x3_wino_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
 int adain_conv3x3_wino(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,
                        int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out,
-                       int m_tiles /* 32-tile M-tiles per workgroup: 2 (8 waves, 8x32 px) or 1 (4 waves, 4x32 px) */,
+                       int form /* 3: A operand transformed in registers (default of encode/decode; cin % 16 == 0); 1 / 2: transformed
+                                    input staged in LDS, 1 or 2 32-tile M-tiles per workgroup */,
                        adain_stream_t stream);
 
 #ifdef __cplusplus

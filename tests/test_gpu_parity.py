@@ -105,7 +105,7 @@ def test_conv3x3_tile_variants_and_fused_output_pool(rt, variant, shape):
             rt.conv3x3(xg, packed, b.cuda(), cout, rt.SRC_DIRECT, relu=True, pool_out=True, variant=variant)
 
 
-@pytest.mark.parametrize("m_tiles", [2, 1])
+@pytest.mark.parametrize("m_tiles", [2, 1, 3])
 @pytest.mark.parametrize("mode", ["direct", "up"])
 @pytest.mark.parametrize("shape", [(1, 128, 128, 16, 32), (2, 128, 64, 9, 37), (1, 256, 128, 21, 70), (1, 512, 256, 5, 6), (1, 64, 64, 8, 8)])
 def test_conv3x3_winograd_vs_oracle(rt, mode, shape, m_tiles):
