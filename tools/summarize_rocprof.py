@@ -62,7 +62,7 @@ def traffic(fetch_dir, write_dir, key, out_json):
         n, v = 0, 0.0
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if ("conv3x3_mfma_kernel" in r["Kernel_Name"] or "conv3x3_persist_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
+                if "conv3x3_" in r["Kernel_Name"] and "pack_" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
                     n += 1
                     v += float(r["Counter_Value"])
         return n, v
@@ -76,7 +76,7 @@ def traffic(fetch_dir, write_dir, key, out_json):
         d = {}
     d[key] = {"hbm_bytes_per_conv3x3_launch": round(per_launch), "fetch_kb_per_launch_raw": round(f / nf, 1),
               "write_kb_per_launch": round(w / nw, 1), "dispatches": nf,
-              "note": "2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, averaged over every conv3x3_mfma_kernel / conv3x3_persist_kernel dispatch of bench.py"}
+              "note": "2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, averaged over every conv3x3_* (wino2 / mfma / persist) dispatch of bench.py"}
     json.dump(d, open(out_json, "w"), indent=1, sort_keys=True)
     print(json.dumps(d[key]))
 
