@@ -27,6 +27,7 @@
 //     (all 128 KiB), then every lane owns one channel and finishes Y = A^T P for 8 tiles: bias, ReLU,
 //     optional 2x2 max-pool of the output (the 4 outputs of a Winograd tile ARE one pool window), stores of
 //     256 contiguous bytes per pixel.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -316,6 +317,9 @@ __global__ __launch_bounds__(MH * 256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 // the raw halo image, combines them (16 + 16 adds) and holds the four A fragments of the next chunk in registers:
 // no V image (48 KB), no V stores, no A-fragment reads, and the raw halo is staged 16 channels at a time, so the
 // workgroup barrier comes once per 64 MFMAs per wave instead of once per 32.
+// (The patch reads have 2-way LDS bank conflicts; a 1-bit XOR swizzle of the channel quads removes them and measured
+// 3-4 % SLOWER — the extra address arithmetic costs more than the conflicts; timing-only builds: without the input
+// transform +17 %, without staging + barrier +6 %, without weight loads +5 %.)
 // ---------------------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
@@ -336,11 +340,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
 
     const int tiles = a.tiles_x * a.tiles_y;
     const int nct = a.cout / 64;
-    int lid = blockIdx.x;
-    if (a.xcd_order && (gridDim.x & 7) == 0) lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
-    const int ct = lid % nct; lid /= nct;
-    const int pt = lid % tiles;
-    const int img = lid / tiles;
+    int lid = blockIdx.x, ct, pt, img;
+    if (a.xcd_order == 1) {          // channel tile fastest inside a contiguous per-XCD range (halo reuse in L2)
+        if ((gridDim.x & 7) == 0) lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
+        ct = lid % nct; lid /= nct;
+        pt = lid % tiles;
+        img = lid / tiles;
+    } else if (a.xcd_order == 2) {   // pixel tile fastest inside a contiguous per-XCD range (weight reuse in L2)
+        if ((gridDim.x & 7) == 0) lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
+        pt = lid % tiles; lid /= tiles;
+        ct = lid % nct;
+        img = lid / nct;
+    } else {                         // plain: pixel tile fastest, round-robin over XCDs
+        pt = lid % tiles; lid /= tiles;
+        ct = lid % nct;
+        img = lid / nct;
+    }
     const int tx0 = (pt % a.tiles_x) * 32, ty0 = (pt / a.tiles_x) * 4;
     const int nst = a.cin / KR;
 
@@ -553,7 +568,8 @@ int launch_conv3x3_wino(const ConvArgs& a0, int src_mode, int mh, hipStream_t s)
     a.tiles_y = (a.H + 4 * geo - 1) / (4 * geo);
     const long long blocks = (long long)a.tiles_x * a.tiles_y * (a.cout / 64) * a.n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv3x3_wino: bad grid %lld", blocks); return -1; }
-    a.xcd_order = 1;
+    static const int xcd_env = getenv("ADAIN_XCD_ORDER") ? atoi(getenv("ADAIN_XCD_ORDER")) : 1;
+    a.xcd_order = xcd_env;
     const dim3 g((unsigned)blocks);
     const bool up = src_mode == SRC_UP2X;
     if (mh == 3 && a.cin % 16 == 0) {
