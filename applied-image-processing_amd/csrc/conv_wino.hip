@@ -321,7 +321,7 @@ __global__ __launch_bounds__(MH * 256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 // 3-4 % SLOWER — the extra address arithmetic costs more than the conflicts; timing-only builds: without the input
 // transform +17 %, without staging + barrier +6 %, without weight loads +5 %.)
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool PIN = true>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
     constexpr int KR = 16;                  // channels per raw stage = 2 MFMA chunks of 8
     constexpr int RSTR = KR + 4;            // floats per halo pixel (80 B: conflict-free b128 for 16 distinct tiles)
@@ -448,6 +448,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(use[j][s], bq[j % RING][n][s], acc[j][n], 0, 0, 0);
+            if constexpr (PIN) {
+                // weight prefetch first, then one MFMA followed by one slice of the transform: a patch read (step 0) or
+                // four adds (step 2), so the wave's non-matrix work issues in the shadow of its own MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+#define W2_SLOT                                                                                  \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
+                if constexpr (j == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         \
+                if constexpr (j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                W2_SLOT W2_SLOT W2_SLOT W2_SLOT W2_SLOT W2_SLOT W2_SLOT W2_SLOT
+#undef W2_SLOT
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         step(std::integral_constant<int, 0>{});
