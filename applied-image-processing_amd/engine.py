@@ -117,3 +117,35 @@ def precompute_guides(engine, views, names, output_dir, masks=None, content_size
 def pooled_style_embedding(style_f):
     """[1,512,h,w] relu4_1 features -> [1,512] (reference Style_3DGS/train.py:80-84: adaptive_avg_pool2d + view)."""
     return style_f.float().mean(dim=(2, 3)).view(style_f.shape[0], style_f.shape[1])
+
+
+class GraphedStylize:
+    """The whole ``engine.stylize`` pass (about 30 kernel launches) captured once into a hipGraph and replayed with one
+    launch per batch — for the reference's real-world sizes (256 or 512 pixel frames, video/utils.py:264,
+    test.py:160) the per-kernel launch overhead of the eager path is a visible share of a 1-2 ms forward.
+    Every C-ABI entry point only enqueues work on the given stream and neither allocates nor synchronises, which is
+    what makes the capture legal.  The style must be set before capture (its statistics are baked into the graph's
+    input buffers by reference, so ``engine.set_style`` followed by a new capture is needed to change it)."""
+
+    def __init__(self, engine, n, h, w, alpha=0.5, to_u8=False):
+        self.engine = engine
+        self.static_in = torch.zeros((n, 3, h, w), dtype=torch.float32, device=engine.device)
+        side = torch.cuda.Stream(engine.device)
+        side.wait_stream(torch.cuda.current_stream(engine.device))
+        with torch.cuda.stream(side):            # warm-up outside the capture: workspaces, lazy library state
+            for _ in range(2):
+                out = engine.stylize(self.static_in, alpha)
+                if to_u8:
+                    out = engine.to_u8(out)
+        torch.cuda.current_stream(engine.device).wait_stream(side)
+        torch.cuda.synchronize(engine.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            out = engine.stylize(self.static_in, alpha)
+            self.static_out = engine.to_u8(out) if to_u8 else out
+
+    def __call__(self, content):
+        """content [n,3,h,w] (GPU or pinned host tensor) -> the graph's output buffer (overwritten by the next call)."""
+        self.static_in.copy_(content, non_blocking=True)
+        self.graph.replay()
+        return self.static_out

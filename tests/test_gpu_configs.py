@@ -120,3 +120,16 @@ def test_run_depth_cli_offline(weights, tmp_path):
                         "--decoder", str(tmp_path / "dec.pth")])
     assert p == tmp_path / "o" / "stylized.jpg" and p.exists()
     assert Image.open(p).size == (616, 512)      # content_size=512 default: 80x96 -> 512x614 -> decoder 8*ceil: 512x616
+
+
+def test_graph_replay_is_bitwise_identical(engine):
+    """The C ABI only enqueues work (no allocation, no synchronisation inside), so a whole stylize pass can be captured
+    into a hipGraph; the replay must give exactly the eager result."""
+    from applied_image_processing_amd.engine import GraphedStylize
+
+    x = T(synth.image(201, 2, 96, 160)).cuda()
+    g = GraphedStylize(engine, 2, 96, 160, alpha=0.5, to_u8=True)
+    want = engine.to_u8(engine.stylize(x, 0.5))
+    assert torch.equal(g(x), want)
+    y = T(synth.image(202, 2, 96, 160)).cuda()
+    assert torch.equal(g(y), engine.to_u8(engine.stylize(y, 0.5)))
