@@ -133,3 +133,69 @@ def test_graph_replay_is_bitwise_identical(engine):
     assert torch.equal(g(x), want)
     y = T(synth.image(202, 2, 96, 160)).cuda()
     assert torch.equal(g(y), engine.to_u8(engine.stylize(y, 0.5)))
+
+
+def _hashf(tag, n):
+    """numpy mirror of hashf() in examples/c_abi_smoke.c (uint32 wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        i = np.arange(n, dtype=np.uint32)
+        x = (np.uint32(tag) * np.uint32(0x9E3779B1)) ^ (i * np.uint32(0x85EBCA77))
+        x ^= x >> np.uint32(15); x *= np.uint32(0x2C1B3C6D)
+        x ^= x >> np.uint32(12); x *= np.uint32(0x297A2D39)
+        x ^= x >> np.uint32(15)
+    return (x >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0) - np.float32(0.5)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The boundary is a C ABI: a plain-C program (no Python, no torch) linked against libadain_hip.so runs the whole
+    path; its uint8 image must equal, bit for bit, what the Python surface produces from the same weights and inputs."""
+    import os
+    import re
+    import shutil
+    import subprocess
+
+    from conftest import ROOT
+    import applied_image_processing_amd.runtime as rt
+
+    cc = shutil.which("cc") or shutil.which("gcc")
+    if cc is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("no C compiler / ROCm headers on this box")
+    pkg = os.path.dirname(rt.LIB_PATH)
+    exe = tmp_path / "c_abi_smoke"
+    subprocess.run([cc, "-O2", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    os.path.join(ROOT, "examples", "c_abi_smoke.c"), "-o", str(exe), "-L", pkg, "-ladain_hip",
+                    "-L", "/opt/rocm/lib", "-lamdhip64", "-lm"], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=pkg + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    H, W, Hs, Ws = 72, 104, 64, 80
+    r = subprocess.run([str(exe), str(H), str(W), str(Hs), str(Ws)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"-> (\d+)x(\d+) image, sum (\d+), fnv ([0-9a-f]{16})", r.stdout)
+    assert m, r.stdout
+
+    # the same weights / inputs through the Python surface
+    enc = [(3, 3, 1), (3, 64, 3), (64, 64, 3), (64, 128, 3), (128, 128, 3), (128, 256, 3), (256, 256, 3), (256, 256, 3),
+           (256, 256, 3), (256, 512, 3)]
+    dec = [(512, 256, 3), (256, 256, 3), (256, 256, 3), (256, 256, 3), (256, 128, 3), (128, 128, 3), (128, 64, 3),
+           (64, 64, 3), (64, 3, 3)]
+    vgg_sd, dec_sd = {}, {}
+    for i, ((cin, cout, k), key) in enumerate(zip(enc, rt.ENC_KEYS)):
+        bound = np.sqrt(np.float32(6.0) / np.float32(cin * k * k), dtype=np.float32)
+        vgg_sd[f"{key}.weight"] = T((_hashf(100 + i, cout * cin * k * k) * (np.float32(2.0) * bound)).reshape(cout, cin, k, k))
+        vgg_sd[f"{key}.bias"] = T(_hashf(200 + i, cout) * np.float32(0.1))
+    for i, ((cin, cout, k), key) in enumerate(zip(dec, rt.DEC_KEYS)):
+        bound = np.sqrt(np.float32(6.0) / np.float32(cin * 9), dtype=np.float32)
+        dec_sd[f"{key}.weight"] = T((_hashf(300 + i, cout * cin * 9) * (np.float32(2.0) * bound)).reshape(cout, cin, 3, 3))
+        dec_sd[f"{key}.bias"] = T(_hashf(400 + i, cout) * np.float32(0.1))
+    from applied_image_processing_amd.engine import AdaINEngine
+
+    e = AdaINEngine(vgg_sd, dec_sd, "cuda:0")
+    content = T((_hashf(1, 3 * H * W) + np.float32(0.5)).reshape(1, 3, H, W)).cuda()
+    style = T((_hashf(2, 3 * Hs * Ws) + np.float32(0.5)).reshape(1, 3, Hs, Ws)).cuda()
+    e.set_style(style)
+    u8 = e.to_u8(e.stylize(content, 0.5)).cpu().numpy().reshape(-1)
+    assert (int(m.group(1)), int(m.group(2))) == (72, 104)
+    assert int(m.group(3)) == int(u8.astype(np.uint64).sum())
+    fnv = 1469598103934665603
+    for b in u8.tolist():
+        fnv = ((fnv ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert m.group(4) == f"{fnv:016x}"
