@@ -226,9 +226,8 @@ int launch_quantize_u8(const float* in, uint8_t* out, int n, int c, int h, int w
 // ---- video post-pass (reference video/utils.py:89-105 warp_image, :223-229 blend_images) -------------------
 // out = u8( clip( (alpha * cur/255 + (1 - alpha) * warp(prev)/255) * 255, 0, 255 ) ), HWC uint8 frames;
 // warp(prev)(y, x) = bilinear sample of prev at (x + flow[0][y][x], y + flow[1][y][x]) with cv2.BORDER_REFLECT
-// (fedcba|abcdefgh|hgfedcb), rounded to uint8 like cv2.remap's uint8 output.  cv2 interpolates uint8 in 5-bit
-// fixed point; this kernel interpolates in fp32, so results can differ from OpenCV by 1 LSB (parity unpinned:
-// cv2 is not installed in the build image).
+// (fedcba|abcdefgh|hgfedcb), in cv2.remap's own uint8 fixed-point arithmetic (below).  cv2 is not installed in the build
+// image, so the fixed-point restatement is checked against the oracle only (parity unpinned against OpenCV itself).
 __device__ __forceinline__ int reflect_border(int v, int n) {
     const int p = 2 * n;      // BORDER_REFLECT has period 2n: ...cba|abc...xyz|zyx...
     v %= p;
@@ -236,6 +235,14 @@ __device__ __forceinline__ int reflect_border(int v, int n) {
     return v < n ? v : p - 1 - v;
 }
 
+// cv2.remap(uint8, float maps, INTER_LINEAR) is fixed point (OpenCV imgwarp: INTER_BITS = 5, INTER_REMAP_COEF_BITS = 15):
+// the map is rounded half-to-even to 1/32 pixel, the four weights are (32-fx)(32-fy)*32 ... (they sum to 2^15; the one
+// saturated entry {32767,0,0,1} at fx = fy = 0 cannot change a rounded result) and the pixel is
+// (sum(S*w) + 2^14) >> 15.  Integer from the map rounding on, so the warp is bit-exact against the oracle; the blend that
+// follows is the reference's float32 numpy expression evaluated without contraction.
+__device__ __forceinline__ int clamp_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+#pragma clang fp contract(off)
 __global__ __launch_bounds__(256) void warp_blend_u8_kernel(const uint8_t* __restrict__ cur, const uint8_t* __restrict__ prev,
                                                             const float* __restrict__ flow, uint8_t* __restrict__ out, int h, int w,
                                                             int c, float alpha, float one_minus_alpha) {
@@ -243,17 +250,19 @@ __global__ __launch_bounds__(256) void warp_blend_u8_kernel(const uint8_t* __res
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int y = i / w, x = i - y * w;
         const float mx = (float)x + flow[i], my = (float)y + flow[(size_t)total + i];
-        const float fx0 = floorf(mx), fy0 = floorf(my);
-        const float ax = mx - fx0, ay = my - fy0;
-        const int x0 = reflect_border((int)fx0, w), x1 = reflect_border((int)fx0 + 1, w);
-        const int y0 = reflect_border((int)fy0, h), y1 = reflect_border((int)fy0 + 1, h);
+        const int ix = __float2int_rn(mx * 32.0f), iy = __float2int_rn(my * 32.0f);
+        const int sx = clamp_short(ix >> 5), sy = clamp_short(iy >> 5), fx = ix & 31, fy = iy & 31;
+        const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+        const int x0 = reflect_border(sx, w), x1 = reflect_border(sx + 1, w);
+        const int y0 = reflect_border(sy, h), y1 = reflect_border(sy + 1, h);
         for (int ch = 0; ch < c; ++ch) {
-            const float p00 = prev[((size_t)y0 * w + x0) * c + ch], p01 = prev[((size_t)y0 * w + x1) * c + ch];
-            const float p10 = prev[((size_t)y1 * w + x0) * c + ch], p11 = prev[((size_t)y1 * w + x1) * c + ch];
-            const float top = p00 + ax * (p01 - p00), bot = p10 + ax * (p11 - p10);
-            const float wv = floorf(fminf(fmaxf(top + ay * (bot - top), 0.f), 255.f) + 0.5f);   // cv2 rounds to uint8
-            const float b = alpha * ((float)cur[(size_t)i * c + ch] / 255.0f) + one_minus_alpha * (wv / 255.0f);
-            out[(size_t)i * c + ch] = (uint8_t)fminf(fmaxf(b * 255.f, 0.f), 255.f);
+            const int p00 = prev[((size_t)y0 * w + x0) * c + ch], p01 = prev[((size_t)y0 * w + x1) * c + ch];
+            const int p10 = prev[((size_t)y1 * w + x0) * c + ch], p11 = prev[((size_t)y1 * w + x1) * c + ch];
+            const int wv = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;          // <= 255 by construction
+            const float a = alpha * ((float)cur[(size_t)i * c + ch] / 255.0f);
+            const float bq = one_minus_alpha * ((float)wv / 255.0f);
+            const float b = (a + bq) * 255.0f;
+            out[(size_t)i * c + ch] = (uint8_t)fminf(fmaxf(b, 0.f), 255.f);
         }
     }
 }

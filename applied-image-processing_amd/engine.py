@@ -119,6 +119,23 @@ def pooled_style_embedding(style_f):
     return style_f.float().mean(dim=(2, 3)).view(style_f.shape[0], style_f.shape[1])
 
 
+def temporal_blend(frames_u8, flows, alpha=0.7):
+    """Temporal-consistency post-pass of the video caller (reference video/utils.py:352-369): frame 0 is kept,
+    frame i becomes blend(frame_i, warp(result_{i-1}, flow_{i-1}), alpha).  ``frames_u8`` [n,h,w,c] uint8 stylised
+    frames already at the target resolution, ``flows`` [n-1,2,h,w] float32 (prev -> current, caller-supplied: the
+    optical-flow estimator stays outside), both on the GPU.  The recurrence is sequential over frames, so it runs
+    on one rank over the gathered frames; each step is one pixel kernel."""
+    n = frames_u8.shape[0]
+    if flows.shape[0] != max(n - 1, 0):
+        raise rt.AdainHipError("temporal_blend: need one flow field per consecutive frame pair")
+    out = torch.empty_like(frames_u8)
+    if n:
+        out[0].copy_(frames_u8[0])
+    for i in range(1, n):
+        out[i].copy_(rt.warp_blend_u8(frames_u8[i], out[i - 1], flows[i - 1], alpha))
+    return out
+
+
 class GraphedStylize:
     """The whole ``engine.stylize`` pass (about 30 kernel launches) captured once into a hipGraph and replayed with one
     launch per batch — for the reference's real-world sizes (256 or 512 pixel frames, video/utils.py:264,

@@ -110,7 +110,8 @@ int adain_quantize_u8(const float* image_nchw, uint8_t* out_nhwc, int n, int c, 
 /* ---- video post-pass (reference video/utils.py:89-105 warp_image + :223-229 blend_images) -------------------
  * HWC uint8 frames [h][w][c]; flow [2][h][w] (x then y displacement, as estimate_optical_flow returns it,
  * video/utils.py:75-86).  out = u8(clip((alpha*cur/255 + one_minus_alpha*warp(prev)/255)*255, 0, 255)), warp =
- * bilinear remap with BORDER_REFLECT.  The optical-flow estimate itself stays with the caller (OpenCV). */
+ * cv2.remap(INTER_LINEAR, BORDER_REFLECT) in OpenCV's uint8 fixed point (map rounded to 1/32 px, 2^15-scaled weights,
+ * (sum + 2^14) >> 15).  The optical-flow estimate itself stays with the caller (OpenCV). */
 int adain_warp_blend_u8(const uint8_t* cur_u8, const uint8_t* prev_u8, const float* flow, uint8_t* out_u8, int h, int w,
                         int c, float alpha, float one_minus_alpha, adain_stream_t stream);
 

@@ -150,27 +150,51 @@ def psnr(a, b):
     return 20 * torch.log10(1.0 / torch.sqrt(mse))
 
 
-def warp_blend_u8(cur, prev, flow, alpha):
-    """Reference video/utils.py:89-105 (warp_image: remap INTER_LINEAR, BORDER_REFLECT) + :223-229
-    (blend_images) on uint8 HWC numpy frames; flow [2,H,W].  numpy restatement with fp32 bilinear weights;
-    PARITY UNPINNED against OpenCV (cv2 absent): cv2.remap interpolates uint8 in 5-bit fixed point."""
+def warp_u8(prev, flow):
+    """Reference video/utils.py:89-105 (warp_image): cv2.remap(uint8 HWC, x + flow[0], y + flow[1], INTER_LINEAR,
+    BORDER_REFLECT).  cv2 is a third-party dependency absent from this image (requirements.txt:6 opencv-contrib-python,
+    version not pinned); this restates OpenCV 4.x's published fixed-point path (modules/imgproc/src/imgwarp.cpp:
+    RemapInvoker map conversion + remapBilinear<FixedPtCast<int, uchar, 15>>, INTER_BITS = 5): map rounded half-to-even
+    to 1/32 px, bilinear weights from the 32x32 table scaled to 2^15, (sum + 2^14) >> 15, borderInterpolate(REFLECT).
+    PARITY UNPINNED against OpenCV itself (no cv2 here to generate vectors)."""
     import numpy as np
 
-    h, w, c = cur.shape
+    h, w, c = prev.shape
     x, y = np.meshgrid(np.arange(w), np.arange(h))
-    mx = (x + flow[0]).astype(np.float32)
+    mx = (x + flow[0]).astype(np.float32)                  # video/utils.py:98-99
     my = (y + flow[1]).astype(np.float32)
-    x0f, y0f = np.floor(mx), np.floor(my)
-    ax, ay = (mx - x0f)[..., None], (my - y0f)[..., None]
+    ix = np.rint(mx * np.float32(32)).astype(np.int64)     # cvRound(sX * INTER_TAB_SIZE)
+    iy = np.rint(my * np.float32(32)).astype(np.int64)
+    sx, sy = np.clip(ix >> 5, -32768, 32767), np.clip(iy >> 5, -32768, 32767)   # saturate_cast<short>
+    fx, fy = (ix & 31)[..., None], (iy & 31)[..., None]
 
-    def refl(v, n):
-        v = np.mod(v.astype(np.int64), 2 * n)          # BORDER_REFLECT: fedcba|abcdefgh|hgfedcb, period 2n
+    def refl(v, n):                                        # borderInterpolate(BORDER_REFLECT): fedcba|abcdefgh|hgfedcb
+        v = np.mod(v, 2 * n)
         return np.where(v < n, v, 2 * n - 1 - v)
 
-    x0, x1, y0, y1 = refl(x0f, w), refl(x0f + 1, w), refl(y0f, h), refl(y0f + 1, h)
-    p = prev.astype(np.float32)
-    top = p[y0, x0] + ax * (p[y0, x1] - p[y0, x0])
-    bot = p[y1, x0] + ax * (p[y1, x1] - p[y1, x0])
-    warped = np.floor(np.clip(top + ay * (bot - top), 0, 255) + np.float32(0.5)).astype(np.float32)
-    blended = np.float32(alpha) * (cur.astype(np.float32) / np.float32(255.0)) + np.float32(1 - alpha) * (warped / np.float32(255.0))
+    x0, x1, y0, y1 = refl(sx, w), refl(sx + 1, w), refl(sy, h), refl(sy + 1, h)
+    p = prev.astype(np.int64)
+    acc = (p[y0, x0] * ((32 - fx) * (32 - fy) * 32) + p[y0, x1] * (fx * (32 - fy) * 32)
+           + p[y1, x0] * ((32 - fx) * fy * 32) + p[y1, x1] * (fx * fy * 32) + (1 << 14)) >> 15
+    return acc.astype(np.uint8)
+
+
+def warp_blend_u8(cur, prev, flow, alpha):
+    """warp_u8 followed by reference video/utils.py:223-229 (blend_images, numpy float32 semantics) on uint8 HWC frames;
+    flow [2,H,W]."""
+    import numpy as np
+
+    warped = warp_u8(prev, flow).astype(np.float32) / np.float32(255.0)
+    blended = np.float32(alpha) * (cur.astype(np.float32) / np.float32(255.0)) + np.float32(1 - alpha) * warped
     return np.clip(blended * np.float32(255), 0, 255).astype(np.uint8)
+
+
+def temporal_blend(frames, flows, alpha):
+    """The frame-to-frame recurrence of video/utils.py:352-369 on already stylised uint8 frames [n,H,W,C]:
+    frame 0 is kept; frame i = blend(frame_i, warp(result_{i-1}, flow_{i-1}))."""
+    import numpy as np
+
+    out = [frames[0]]
+    for i in range(1, len(frames)):
+        out.append(warp_blend_u8(frames[i], out[-1], flows[i - 1], alpha))
+    return np.stack(out)
