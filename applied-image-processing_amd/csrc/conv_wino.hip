@@ -321,7 +321,7 @@ __global__ __launch_bounds__(MH * 256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 // 3-4 % SLOWER — the extra address arithmetic costs more than the conflicts; timing-only builds: without the input
 // transform +17 %, without staging + barrier +6 %, without weight loads +5 %.)
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE, bool PIN = true>
+template <int MODE, bool PIN = true, int DIAG = 0>   // DIAG 1: per-block time stamps; 2: + LDS padded to one block per CU
 __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
     constexpr int KR = 16;                  // channels per raw stage = 2 MFMA chunks of 8
     constexpr int RSTR = KR + 4;            // floats per halo pixel (80 B: conflict-free b128 for 16 distinct tiles)
@@ -330,8 +330,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
     constexpr int PEX = 4 * 2 * 32 * 64;    // epilogue exchange (64 KiB) >= 2 raw buffers
     constexpr int RITEMS = (HALO * 4 + 255) / 256;
     static_assert(2 * RBUF <= PEX, "LDS layout");
-    __shared__ __attribute__((aligned(16))) float smem[PEX];
+    __shared__ __attribute__((aligned(16))) float smem[DIAG == 2 ? PEX + 8192 : PEX];
     float* const Rs = smem;
+    unsigned long long stamp[4] = {0, 0, 0, 0};
+    if constexpr (DIAG) stamp[0] = __builtin_amdgcn_s_memrealtime();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -476,6 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
     if (nst > 1) raw_load(1);
     xf_read(Rs);
     xf_make(aq0);
+    if constexpr (DIAG) stamp[1] = __builtin_amdgcn_s_memrealtime();
 
     for (int s = 0; s < nst; ++s) {
         const float* cur = Rs + (s & 1) * RBUF;
@@ -487,6 +490,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
         if (s + 2 < nst) raw_load(s + 2);
         chunk(aq1, aq0, nxt, more);                     // channels 8..15; prepares the next stage's first chunk
     }
+    if constexpr (DIAG) stamp[2] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
 
     // ---- epilogue: identical to conv3x3_wino_kernel<MODE, 1> ----------------------------------------------------------------
@@ -550,6 +554,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
             }
         }
     }
+    if constexpr (DIAG) {
+        stamp[3] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && a.dbg) {     // [block][wave][4 stamps], then [block] hardware ids
+            unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wi) * 4;
+            d[0] = stamp[0]; d[1] = stamp[1]; d[2] = stamp[2]; d[3] = stamp[3];
+            if (wi == 0) a.dbg[(size_t)gridDim.x * 16 + blockIdx.x] =
+                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        }
+    }
 }
 
 int launch_pack_wino(const float* w, float* p, int cin, int cout, hipStream_t s) {
@@ -583,7 +596,10 @@ int launch_conv3x3_wino(const ConvArgs& a0, int src_mode, int mh, hipStream_t s)
     a.xcd_order = xcd_env;
     const dim3 g((unsigned)blocks);
     const bool up = src_mode == SRC_UP2X;
-    if (mh == 3 && a.cin % 16 == 0) {
+    if ((mh == 13 || mh == 14) && a.cin % 16 == 0 && !up) {      // diagnostic builds (tools/wino_probe.py)
+        if (mh == 13) hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT, true, 1>), g, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT, true, 2>), g, dim3(256), 0, s, a);
+    } else if (mh == 3 && a.cin % 16 == 0) {
         if (up) hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_UP2X>), g, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a);
     } else if (mh == 2) {
