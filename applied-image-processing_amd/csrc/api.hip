@@ -343,7 +343,7 @@ int adain_conv3x3_wino(const float* in, float* out, const float* packed_w, const
                        int cin, int cout, int src_mode, int relu, int pool_out, int mh, adain_stream_t stream) {
     if (!in || !out || !packed_w || !bias) { set_error("conv3x3_wino: null pointer"); return ADAIN_EINVAL; }
     ConvArgs a{};
-    a.dbg = (mh == 13 || mh == 14) ? g_conv_dbg : nullptr;
+    a.dbg = (mh >= 13 && mh <= 16) ? g_conv_dbg : nullptr;
     a.in = in; a.out = out; a.wpk = packed_w; a.bias = bias;
     a.n = n; a.H = h; a.W = w; a.Hs = hs; a.Ws = ws; a.cin = cin; a.cout = cout; a.relu = relu; a.pool_out = pool_out ? 1 : 0;
     return launch_conv3x3_wino(a, src_mode, mh, (hipStream_t)stream);

@@ -321,16 +321,21 @@ __global__ __launch_bounds__(MH * 256, 2) void conv3x3_wino_kernel(ConvArgs a) {
 // 3-4 % SLOWER — the extra address arithmetic costs more than the conflicts; timing-only builds: without the input
 // transform +17 %, without staging + barrier +6 %, without weight loads +5 %.)
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE, bool PIN = true, int DIAG = 0>   // DIAG 1: per-block time stamps; 2: + LDS padded to one block per CU
-__global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
+// DIAG 1: per-wave phase stamps; 2: + LDS padded to one block per CU; 3 / 4: + a shader-clock stamp per MFMA step of the
+// first 32 workgroups (3: one block per CU, 4: two)
+template <int MODE, bool PIN = true, int DIAG = 0>
+__global__ __launch_bounds__(256, (DIAG == 2 || DIAG == 3) ? 1 : 2) void conv3x3_wino2_kernel(ConvArgs a) {
     constexpr int KR = 16;                  // channels per raw stage = 2 MFMA chunks of 8
     constexpr int RSTR = KR + 4;            // floats per halo pixel (80 B: conflict-free b128 for 16 distinct tiles)
     constexpr int HALO = 6 * WHALO_W;       // 6 x 34 halo of a 4 x 32 pixel tile
-    constexpr int RBUF = HALO * RSTR;       // 4080 floats
+    constexpr int RBUF = 256 * RSTR;        // 204 halo pixels, rounded up to the 4 x 256 staging items (no predicated stores)
     constexpr int PEX = 4 * 2 * 32 * 64;    // epilogue exchange (64 KiB) >= 2 raw buffers
-    constexpr int RITEMS = (HALO * 4 + 255) / 256;
+    constexpr int RITEMS = 4;
+    static_assert(HALO * 4 <= RITEMS * 256, "staging items");
     static_assert(2 * RBUF <= PEX, "LDS layout");
-    __shared__ __attribute__((aligned(16))) float smem[DIAG == 2 ? PEX + 8192 : PEX];
+    __shared__ __attribute__((aligned(16))) float smem[(DIAG == 2 || DIAG == 3) ? PEX + 8192 : (DIAG == 4 ? PEX + 4096 : PEX)];
+    unsigned* const steplog = (unsigned*)(smem + PEX);     // DIAG >= 3: [wave][128] low words of s_memtime
+    int nlog = 0;
     float* const Rs = smem;
     unsigned long long stamp[4] = {0, 0, 0, 0};
     if constexpr (DIAG) stamp[0] = __builtin_amdgcn_s_memrealtime();
@@ -383,15 +388,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
     auto raw_store = [&](float* buf) {
 #pragma unroll
         for (int k = 0; k < RITEMS; ++k) {
-            const int idx = tid + k * 256;
-            if (idx < HALO * 4) *(f32x4*)(buf + (idx >> 2) * RSTR + (idx & 3) * 4) = rawreg[k];
+            const int idx = tid + k * 256;          // items past the halo land in the buffer's unused tail
+            *(f32x4*)(buf + (idx >> 2) * RSTR + (idx & 3) * 4) = rawreg[k];
         }
     };
 
     // ---- this lane's share of the input transform ------------------------------------------------------------------
     // patch of tile li starts at halo pixel (2 * (li >> 4), 2 * (li & 15)); rows (rA, rB) feed transform row wi:
     //   wi 0: d0 - d2   wi 1: d1 + d2   wi 2: d2 - d1   wi 3: d1 - d3      then across columns: e0-e2, e1+e2, e2-e1, e1-e3
-    const int rA = wi == 0 ? 0 : 1, rB = wi == 3 ? 3 : 2;
+    // The whole main loop is instantiated once per transform row (WI is a compile-time constant inside): with a run-time
+    // `wi` the compiler turns the sign selection into scalar branches around every group of four adds, which splits the
+    // MFMA steps into many basic blocks and leaves the transform outside the matrix pipe's shadow (tools/wino_probe.py:
+    // 1200-1300 cycles for a step with the transform against 630 for one without, ideal 512).
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
+
+    auto main_loop = [&](auto WIC) {
+    constexpr int WI = decltype(WIC)::value;
+    constexpr int rA = WI == 0 ? 0 : 1, rB = WI == 3 ? 3 : 2;
     const int p_base = ((2 * (li >> 4)) * WHALO_W + 2 * (li & 15)) * RSTR + 4 * lh;
     const int pA = p_base + rA * WHALO_W * RSTR, pB = p_base + rB * WHALO_W * RSTR;
     f32x4 dA[4], dB[4];
@@ -406,8 +425,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
         f32x4 e[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            if (wi == 1) e[c] = dA[c] + dB[c];
-            else if (wi == 2) e[c] = dB[c] - dA[c];
+            if constexpr (WI == 1) e[c] = dA[c] + dB[c];
+            else if constexpr (WI == 2) e[c] = dB[c] - dA[c];
             else e[c] = dA[c] - dB[c];
         }
         out[0] = e[0] - e[2];
@@ -420,46 +439,57 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
     const int wvo = lane * 16;
     const int nch = a.cin / WKC;
     int wso = ((ct * 4 + wi) * nch) * 8192;
-    constexpr int PF = 3, RING = 4;
+    constexpr int PF = (DIAG == 2 || DIAG == 3) ? 7 : 3, RING = PF + 1;   // the one-block-per-CU diagnostic forms have 512 registers
     f32x4 bq[RING][2];
 #pragma unroll
     for (int p = 0; p < PF; ++p)
 #pragma unroll
         for (int n = 0; n < 2; ++n) bq[p][n] = buf_load4(wsr, wvo, wso + p * 2048 + n * 1024);
 
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
-
     // one chunk of 8 channels: 4 steps of 8 MFMAs on `use`; meanwhile `make` is filled from `nsrc` (next chunk's raw)
-    auto chunk = [&](const f32x4 (&use)[4], f32x4 (&make)[4], const float* nsrc, bool do_xf) {
+    static_assert(RING == 4 || RING == 8, "ring slots follow the step index inside a stage (2 chunks x 4 steps)");
+    auto chunk = [&](const f32x4 (&use)[4], f32x4 (&make)[4], const float* nsrc, auto DOXF, auto HALF) {
+        constexpr bool do_xf = decltype(DOXF)::value;
+        constexpr int half = decltype(HALF)::value;
         auto step = [&](auto JJ) {
             constexpr int j = decltype(JJ)::value;
+            constexpr int g = half * 4 + j;
+            if constexpr (DIAG >= 3) {
+                const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
+                if (lane == 0 && nlog < 128) steplog[wi * 128 + nlog] = tnow;
+                ++nlog;
+            }
 #pragma unroll
-            for (int n = 0; n < 2; ++n) bq[(j + PF) % RING][n] = buf_load4(wsr, wvo, wso + (j + PF) * 2048 + n * 1024);
-            if (do_xf) {
+            for (int n = 0; n < 2; ++n) bq[(g + PF) % RING][n] = buf_load4(wsr, wvo, wso + (j + PF) * 2048 + n * 1024);
+
+            if constexpr (do_xf) {
                 if constexpr (j == 0) xf_read(nsrc);
                 if constexpr (j == 2) xf_make(make);
             }
+            if constexpr (DIAG == 2 || DIAG == 3) {      // experiment: the four MFMAs of one accumulator back to back
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(use[j][s], bq[g % RING][n][s], acc[j][n], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(use[j][s], bq[j % RING][n][s], acc[j][n], 0, 0, 0);
+                    acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(use[j][s], bq[g % RING][n][s], acc[j][n], 0, 0, 0);
+            }
             if constexpr (PIN) {
                 // weight prefetch first, then one MFMA followed by one slice of the transform: a patch read (step 0) or
                 // four adds (step 2), so the wave's non-matrix work issues in the shadow of its own MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+#define W2_LOAD __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
 #define W2_SLOT                                                                                  \
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
-                if constexpr (j == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         \
-                if constexpr (j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                W2_SLOT W2_SLOT W2_SLOT W2_SLOT W2_SLOT W2_SLOT W2_SLOT W2_SLOT
+                if constexpr (do_xf && j == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         \
+                if constexpr (do_xf && j == 2) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                W2_SLOT W2_LOAD W2_SLOT W2_SLOT W2_SLOT W2_SLOT W2_LOAD W2_SLOT W2_SLOT W2_SLOT
 #undef W2_SLOT
+#undef W2_LOAD
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -475,23 +505,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino2_kernel(ConvArgs a) {
     raw_load(0);
     raw_store(Rs);
     __syncthreads();
-    if (nst > 1) raw_load(1);
-    xf_read(Rs);
+    raw_load(1);                                        // stages past the end read the neighbouring channels / pixels or
+    xf_read(Rs);                                        // (out of range) zeros and are never consumed: no branches in the loop
     xf_make(aq0);
     if constexpr (DIAG) stamp[1] = __builtin_amdgcn_s_memrealtime();
 
-    for (int s = 0; s < nst; ++s) {
+    constexpr std::true_type XF{};
+    constexpr std::integral_constant<int, 0> H0{};
+    constexpr std::integral_constant<int, 1> H1{};
+    for (int s = 0; s + 1 < nst; ++s) {
         const float* cur = Rs + (s & 1) * RBUF;
         float* nxt = Rs + ((s + 1) & 1) * RBUF;
-        const bool more = s + 1 < nst;
-        chunk(aq0, aq1, cur + 8, true);                 // channels 0..7 of the stage; prepares channels 8..15
-        if (more) raw_store(nxt);                       // the next stage's halo (loaded one stage ago)
+        chunk(aq0, aq1, cur + 8, XF, H0);               // channels 0..7 of the stage; prepares channels 8..15
+        raw_store(nxt);                                 // the next stage's halo (loaded one stage ago)
         __syncthreads();
-        if (s + 2 < nst) raw_load(s + 2);
-        chunk(aq1, aq0, nxt, more);                     // channels 8..15; prepares the next stage's first chunk
+        raw_load(s + 2);
+        chunk(aq1, aq0, nxt, XF, H1);                   // channels 8..15; prepares the next stage's first chunk
     }
+    chunk(aq0, aq1, Rs + ((nst - 1) & 1) * RBUF + 8, XF, H0);      // last stage: nothing left to stage or prepare
+    chunk(aq1, aq0, Rs, std::false_type{}, H1);
     if constexpr (DIAG) stamp[2] = __builtin_amdgcn_s_memrealtime();
+    };
+    if (wi == 0) main_loop(std::integral_constant<int, 0>{});
+    else if (wi == 1) main_loop(std::integral_constant<int, 1>{});
+    else if (wi == 2) main_loop(std::integral_constant<int, 2>{});
+    else main_loop(std::integral_constant<int, 3>{});
     __syncthreads();
+    if constexpr (DIAG >= 3) {
+        if (a.dbg && blockIdx.x < 32) {
+            unsigned* d32 = (unsigned*)(a.dbg + (size_t)gridDim.x * 17) + blockIdx.x * 512;
+            for (int i = tid; i < 512; i += 256) d32[i] = (i & 127) < nlog ? steplog[i] : 0u;
+        }
+        __syncthreads();
+    }
 
     // ---- epilogue: identical to conv3x3_wino_kernel<MODE, 1> ----------------------------------------------------------------
     {
@@ -596,9 +642,11 @@ int launch_conv3x3_wino(const ConvArgs& a0, int src_mode, int mh, hipStream_t s)
     a.xcd_order = xcd_env;
     const dim3 g((unsigned)blocks);
     const bool up = src_mode == SRC_UP2X;
-    if ((mh == 13 || mh == 14) && a.cin % 16 == 0 && !up) {      // diagnostic builds (tools/wino_probe.py)
+    if (mh >= 13 && mh <= 16 && a.cin % 16 == 0 && !up) {      // diagnostic builds (tools/wino_probe.py)
         if (mh == 13) hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT, true, 1>), g, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT, true, 2>), g, dim3(256), 0, s, a);
+        else if (mh == 14) hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT, true, 2>), g, dim3(256), 0, s, a);
+        else if (mh == 15) hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT, true, 3>), g, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT, true, 4>), g, dim3(256), 0, s, a);
     } else if (mh == 3 && a.cin % 16 == 0) {
         if (up) hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_UP2X>), g, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a);

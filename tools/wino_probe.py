@@ -38,7 +38,7 @@ def probe(cin, cout, h):
     b = torch.zeros(cout, device=dev)
     wp = rt.conv3x3_wino_pack(w)
     nblk = ((h + 31) // 32) * ((h + 3) // 4) * (cout // 64)
-    dbg = torch.zeros(17 * nblk, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(17 * nblk + 8192, dtype=torch.int64, device=dev)
     lib.adain_debug_set_conv_stamp_buffer(dbg.data_ptr())
     flop = 2.0 * h * h * cin * cout * 9
     t0 = time.time()
@@ -47,6 +47,9 @@ def probe(cin, cout, h):
             rt.conv3x3_wino(x, wp, b, cout, rt.SRC_DIRECT, True, False, 3)
         torch.cuda.synchronize()
     print(f"== {cin}->{cout} @{h}: {nblk} workgroups, ideal main loop per workgroup alone {cin / 8 * 2048 / 2.38e3:.1f} us")
+    ref = rt.conv3x3_wino(x, wp, b, cout, rt.SRC_DIRECT, True, False, 3)
+    for form in (13, 14, 15, 16):
+        assert torch.equal(ref, rt.conv3x3_wino(x, wp, b, cout, rt.SRC_DIRECT, True, False, form)), form
     for form in (3, 13, 14):
         us = timed(lambda: rt.conv3x3_wino(x, wp, b, cout, rt.SRC_DIRECT, True, False, form))
         print(f"form {form}: {us:.1f} us/launch = {flop / us / 1e6:.1f} TF/s (algorithmic)")
@@ -57,7 +60,7 @@ def probe(cin, cout, h):
         torch.cuda.synchronize()
         d = dbg.cpu()
         st = d[:16 * nblk].view(nblk, 4, 4).double() / 100.0        # us
-        hw = d[16 * nblk:]
+        hw = d[16 * nblk:17 * nblk]
         st = st - st[:, :, 0].min()
         ent, ls, le, ex = st[:, :, 0], st[:, :, 1], st[:, :, 2], st[:, :, 3]
         span = ex.max()
@@ -98,8 +101,26 @@ def probe(cin, cout, h):
         # lockstep: distribution of main-loop start times modulo nothing -> print entry-time histogram of rounds
         e = ent.min(dim=1).values.sort().values
         print("   entry times (us), every nblk/16-th workgroup:", [round(float(v), 1) for v in e[:: max(1, nblk // 16)]])
+    for form in (15, 16):
+        dbg.zero_()
+        for _ in range(3):
+            rt.conv3x3_wino(x, wp, b, cout, rt.SRC_DIRECT, True, False, form)
+        torch.cuda.synchronize()
+        lg = dbg.cpu()[17 * nblk:].view(torch.int32).view(32, 4, 128).long() & 0xFFFFFFFF
+        nsteps = min(128, cin // 8 * 4)
+        dt = (lg[:, :, 1:nsteps] - lg[:, :, :nsteps - 1]) & 0xFFFFFFFF       # cycles per step, [block][wave][step]
+        dt = dt.double()
+        print(f"-- form {form} ({'one' if form == 15 else 'two'} workgroups per CU): shader cycles per 8-MFMA step (ideal 512), first 32 workgroups")
+        print(f"   all steps: median {dt.median():.0f}  mean {dt.mean():.0f}  p90 {dt.quantile(0.9):.0f}")
+        for k in range(8):
+            sel = dt[:, :, k::8]
+            what = ("A0 wload+patch reads", "A1", "A2 transform adds", "A3 (ends: halo store + barrier)", "B0 halo loads+patch reads", "B1",
+                    "B2 transform adds", "B3")[k]
+            print(f"   step {k} {what:32s}: median {sel.median():.0f}  mean {sel.mean():.0f}  p90 {sel.quantile(0.9):.0f}")
+        w0 = dt[0, 0, :32].tolist()
+        print("   workgroup 0 wave 0, first 32 steps:", [int(v) for v in w0])
     lib.adain_debug_set_conv_stamp_buffer(None)
 
 
-for shape in ((256, 256, 256), (128, 128, 512), (64, 64, 1024)):
+for shape in ((256, 256, 256), (64, 64, 1024)):
     probe(*shape)
