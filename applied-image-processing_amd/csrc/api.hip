@@ -79,7 +79,9 @@ static bool use_winograd() {
 }
 
 static int wino_mh() {
-    static const int mh = getenv("ADAIN_WINO_MH") ? atoi(getenv("ADAIN_WINO_MH")) : 3;   // 3: register-resident A (default); 1, 2: LDS V image
+    // 34 (default): persistent form (4) where the K loop is short (cin <= 64), register-resident-A form (3) elsewhere;
+    // 1, 2: LDS V image forms
+    static const int mh = getenv("ADAIN_WINO_MH") ? atoi(getenv("ADAIN_WINO_MH")) : 34;
     return mh;
 }
 
@@ -87,7 +89,9 @@ static int launch_layer(ConvArgs& a, const float* packed, const Offsets& f, int 
     a.bias = packed + f.b[i];
     if (use_winograd() && src != SRC_POOL2) {
         a.wpk = packed + f.ww[i];
-        return launch_conv3x3_wino(a, src, wino_mh(), s);
+        int mh = wino_mh();
+        if (mh == 34) mh = a.cin <= 64 ? 4 : 3;      // persistent form where the K loop is short (tools/tune_conv.py)
+        return launch_conv3x3_wino(a, src, mh, s);
     }
     a.wpk = packed + f.w[i];
     return launch_conv3x3(a, src, -1, s);
@@ -343,7 +347,7 @@ int adain_conv3x3_wino(const float* in, float* out, const float* packed_w, const
                        int cin, int cout, int src_mode, int relu, int pool_out, int mh, adain_stream_t stream) {
     if (!in || !out || !packed_w || !bias) { set_error("conv3x3_wino: null pointer"); return ADAIN_EINVAL; }
     ConvArgs a{};
-    a.dbg = (mh >= 13 && mh <= 16) ? g_conv_dbg : nullptr;
+    a.dbg = (mh >= 13 && mh <= 17) ? g_conv_dbg : nullptr;
     a.in = in; a.out = out; a.wpk = packed_w; a.bias = bias;
     a.n = n; a.H = h; a.W = w; a.Hs = hs; a.Ws = ws; a.cin = cin; a.cout = cout; a.relu = relu; a.pool_out = pool_out ? 1 : 0;
     return launch_conv3x3_wino(a, src_mode, mh, (hipStream_t)stream);

@@ -41,7 +41,9 @@ int launch_pack_conv_last(const float* w, float* packed, hipStream_t s);
 int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s);   // variant < 0: automatic
 // conv_wino.hip
 int launch_pack_wino(const float* w_oihw, float* packed, int cin, int cout, hipStream_t s);
-int launch_conv3x3_wino(const ConvArgs& a, int src_mode, int mh, hipStream_t s);   // mh: M-tiles per block (1 or 2)
+int launch_conv3x3_wino(const ConvArgs& a, int src_mode, int mh, hipStream_t s);   // mh: kernel form (1, 2: V image in LDS; 3: register A; 4: persistent)
+// conv_wino3.hip
+int launch_conv3x3_wino3(const ConvArgs& a, int src_mode, hipStream_t s);
 int launch_conv_first(const float* img_nchw, float* out_nhwc, const float* packed, const float* bias, int n, int H,
                       int W, hipStream_t s);
 int launch_conv_last(const float* in_nhwc, float* out_nchw, const float* packed, const float* bias, int n, int H,

@@ -633,6 +633,11 @@ int launch_conv3x3_wino(const ConvArgs& a0, int src_mode, int mh, hipStream_t s)
         set_error("conv3x3_wino: unsupported src_mode %d", src_mode);
         return -1;
     }
+    if ((mh == 4 || mh == 17) && a.cin % 16 == 0 && a.cin >= 32) {       // 17: form 4 with time stamps (tools/wino_probe.py)
+        ConvArgs a4 = a0;
+        if (mh == 4) a4.dbg = nullptr;
+        return launch_conv3x3_wino3(a4, src_mode, s);
+    }
     const int geo = mh == 2 ? 2 : 1;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + 4 * geo - 1) / (4 * geo);

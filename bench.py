@@ -213,7 +213,7 @@ def measure_roofline(step, reps):
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
         "traffic": load_pmc_traffic(f"config{step.config}_batch{step.batch}"),
-        "kernel": ("conv3x3_wino2_kernel (Winograd F(2x2,3x3))" if WINOGRAD else "conv3x3_mfma_kernel / conv3x3_persist_kernel") + f" ({len(flops)} launches/step)",
+        "kernel": ("conv3x3_wino2_kernel + conv3x3_wino3_kernel (Winograd F(2x2,3x3))" if WINOGRAD else "conv3x3_mfma_kernel / conv3x3_persist_kernel") + f" ({len(flops)} launches/step)",
         "avg_launch_ms": round(avg_ms, 4), "flop_per_launch_avg": sum(flops) / len(flops),
         # `achieved` counts the ALGORITHMIC flops of the direct 3x3 convolution.  The Winograd F(2x2,3x3)
         # kernel executes 16/36 of those multiplies on the matrix pipe, which is how `frac` can exceed 1.

@@ -105,7 +105,7 @@ def test_conv3x3_tile_variants_and_fused_output_pool(rt, variant, shape):
             rt.conv3x3(xg, packed, b.cuda(), cout, rt.SRC_DIRECT, relu=True, pool_out=True, variant=variant)
 
 
-@pytest.mark.parametrize("m_tiles", [2, 1, 3])
+@pytest.mark.parametrize("m_tiles", [2, 1, 3, 4])
 @pytest.mark.parametrize("mode", ["direct", "up"])
 @pytest.mark.parametrize("shape", [(1, 128, 128, 16, 32), (2, 128, 64, 9, 37), (1, 256, 128, 21, 70), (1, 512, 256, 5, 6), (1, 64, 64, 8, 8)])
 def test_conv3x3_winograd_vs_oracle(rt, mode, shape, m_tiles):
@@ -122,6 +122,27 @@ def test_conv3x3_winograd_vs_oracle(rt, mode, shape, m_tiles):
     close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True, m_tiles=m_tiles).permute(0, 3, 1, 2), F.relu(pre))
     close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=False, m_tiles=m_tiles).permute(0, 3, 1, 2), pre)
     close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True, pool_out=True, m_tiles=m_tiles).permute(0, 3, 1, 2),
+          F.max_pool2d(F.relu(pre), 2, 2, 0, ceil_mode=True))
+
+
+@pytest.mark.parametrize("mode,shape", [("direct", (1, 64, 128, 250, 203)), ("direct", (2, 32, 64, 131, 257)), ("up", (1, 64, 64, 121, 150)),
+                                        ("direct", (3, 128, 64, 6, 40))])
+def test_conv3x3_winograd_persistent_many_tiles(rt, mode, shape):
+    """The persistent form on grids where a workgroup walks several tiles (more tiles than 2 x CUs), ragged edges, several
+    images and channel tiles: every tile hand-over (prefetched halo, weight ring wrap, LDS reuse) is exercised."""
+    n, cin, cout, hs, ws = shape
+    x = T(synth.uniform_sym(410 + cin, (n, cin, hs, ws), 1.0))
+    w = T(synth.uniform_sym(510 + cout, (cout, cin, 3, 3), (6.0 / (9 * cin)) ** 0.5))
+    b = T(synth.uniform_sym(610 + cout, (cout,), 0.1))
+    src = F.interpolate(x, scale_factor=2, mode="nearest") if mode == "up" else x
+    pre = F.conv2d(F.pad(src, (1, 1, 1, 1), mode="reflect"), w, b)
+    xg = x.cuda().permute(0, 2, 3, 1).contiguous()
+    packed = rt.conv3x3_wino_pack(w.cuda())
+    m = rt.SRC_UP2X if mode == "up" else rt.SRC_DIRECT
+    out = rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True, m_tiles=4)
+    close(out.permute(0, 3, 1, 2), F.relu(pre))
+    assert torch.equal(out, rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True, m_tiles=4))      # deterministic
+    close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True, pool_out=True, m_tiles=4).permute(0, 3, 1, 2),
           F.max_pool2d(F.relu(pre), 2, 2, 0, ceil_mode=True))
 
 

@@ -57,10 +57,10 @@ def main():
         wino = rt.conv3x3_wino_pack(w) if cin % 8 == 0 and mode != rt.SRC_POOL2 else None
 
         def run(v):
-            if v in (20, 21, 22):      # Winograd F(2x2,3x3): 20 = 8 waves (2 M-tiles), 21 = 4 waves (1 M-tile)
+            if v in (20, 21, 22, 23):      # Winograd F(2x2,3x3): 20 = 8 waves (2 M-tiles), 21 = 4 waves (1 M-tile)
                 if wino is None:
                     raise rt.AdainHipError("no winograd form")
-                return rt.conv3x3_wino(x, wino, b, cout, mode, True, pool, {20: 2, 21: 1, 22: 3}[v])
+                return rt.conv3x3_wino(x, wino, b, cout, mode, True, pool, {20: 2, 21: 1, 22: 3, 23: 4}[v])
             return rt.conv3x3(x, packed, b, cout, mode, True, pool, v)
 
         flops = 2.0 * h * h * cin * cout * 9
