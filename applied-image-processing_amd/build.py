@@ -11,13 +11,13 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libadain_hip.so")
-SOURCES = ["conv.hip", "conv_wino.hip", "conv_wino3.hip", "stats.hip", "pixel.hip", "api.hip"]
+SOURCES = ["conv.hip", "conv_wino.hip", "conv_wino3.hip", "conv_wino4.hip", "stats.hip", "pixel.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]
 # The MFMA kernels carry their fp32 vector-ALU work (input transform, epilogues) next to the matrix instructions, where
 # v_pk_add_f32 / v_pk_fma_f32 issue far slower than the plain forms (MI355X_MICROARCH.md, "price of one filler beside
 # MFMAs"): keep hipcc from packing f32 pairs in those files.  Measured on the Winograd kernel: +7 %.
 NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-EXTRA_FLAGS = {"conv_wino.hip": NO_PACKED_F32, "conv_wino3.hip": NO_PACKED_F32}
+EXTRA_FLAGS = {"conv_wino.hip": NO_PACKED_F32, "conv_wino3.hip": NO_PACKED_F32, "conv_wino4.hip": NO_PACKED_F32}
 
 
 def _hipcc():

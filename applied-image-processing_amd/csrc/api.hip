@@ -33,10 +33,11 @@ static const Layer DEC[8] = {{512, 256, SRC_DIRECT, 0}, {256, 256, SRC_UP2X, 0},
 static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
 constexpr size_t FIRST_W = 2 * 4 * 64 * 4, FIRST_B = 64, LAST_W = 4 * 9 * 4 * 4 * 3, LAST_B = 3;
 
-// packed layout: [first w][first b] then per generic layer [w direct][b][w winograd], every block 256-B aligned.
-// Both weight forms are kept (28 MB + 50 MB): the Winograd kernel is the default for every generic 3x3 layer,
-// ADAIN_WINOGRAD=0 switches a process back to the direct implicit GEMM (A/B runs, bit-different but equally valid).
-struct Offsets { size_t w[8], b[8], ww[8], first_b, last_w, last_b, total; };
+// packed layout: [first w][first b] then per generic layer [w direct][b][w F(2x2,3x3)][w F(4,3)xF(2,3)], every block
+// 256-B aligned.  All three weight forms are kept (28 + 50 + 75 MB): the F(4,3) x F(2,3) Winograd kernel is the default for
+// every generic 3x3 layer; ADAIN_WINO_MH selects the F(2x2,3x3) kernels, ADAIN_WINOGRAD=0 the direct implicit GEMM (A/B
+// runs, bit-different but equally valid).
+struct Offsets { size_t w[8], b[8], ww[8], w4[8], first_b, last_w, last_b, total; };
 static Offsets enc_offsets() {
     Offsets f{};
     size_t o = 0;
@@ -50,6 +51,8 @@ static Offsets enc_offsets() {
         o += align64(ENC[i].cout);
         f.ww[i] = o;
         o += align64((size_t)ENC[i].cin * ENC[i].cout * 16);
+        f.w4[i] = o;
+        o += align64((size_t)ENC[i].cin * ENC[i].cout * 24);
     }
     f.total = o;
     return f;
@@ -64,6 +67,8 @@ static Offsets dec_offsets() {
         o += align64(DEC[i].cout);
         f.ww[i] = o;
         o += align64((size_t)DEC[i].cin * DEC[i].cout * 16);
+        f.w4[i] = o;
+        o += align64((size_t)DEC[i].cin * DEC[i].cout * 24);
     }
     f.last_w = o;
     o += align64(LAST_W);
@@ -79,9 +84,9 @@ static bool use_winograd() {
 }
 
 static int wino_mh() {
-    // 34 (default): persistent form (4) where the K loop is short (cin <= 64), register-resident-A form (3) elsewhere;
-    // 1, 2: LDS V image forms
-    static const int mh = getenv("ADAIN_WINO_MH") ? atoi(getenv("ADAIN_WINO_MH")) : 34;
+    // 5 (default): F(4,3) x F(2,3); F(2x2,3x3) forms: 34 = persistent form (4) where the K loop is short (cin <= 64) and
+    // register-resident-A form (3) elsewhere; 1, 2: LDS V image forms
+    static const int mh = getenv("ADAIN_WINO_MH") ? atoi(getenv("ADAIN_WINO_MH")) : 5;
     return mh;
 }
 
@@ -90,6 +95,10 @@ static int launch_layer(ConvArgs& a, const float* packed, const Offsets& f, int 
     if (use_winograd() && src != SRC_POOL2) {
         a.wpk = packed + f.ww[i];
         int mh = wino_mh();
+        if (mh == 5) {
+            a.wpk = packed + f.w4[i];
+            return launch_conv3x3_wino4(a, src, s);
+        }
         if (mh == 34) mh = a.cin <= 64 ? 4 : 3;      // persistent form where the K loop is short (tools/tune_conv.py)
         return launch_conv3x3_wino(a, src, mh, s);
     }
@@ -131,6 +140,7 @@ int adain_encoder_pack(const float* const* w, const float* const* b, float* pack
     for (int i = 0; i < 8; ++i) {
         RET_IF(launch_pack_conv3x3(w[i + 2], packed + f.w[i], ENC[i].cin, ENC[i].cout, s));
         RET_IF(launch_pack_wino(w[i + 2], packed + f.ww[i], ENC[i].cin, ENC[i].cout, s));
+        RET_IF(launch_pack_wino4(w[i + 2], packed + f.w4[i], ENC[i].cin, ENC[i].cout, s));
         RET_IF(copy_bias(b[i + 2], packed + f.b[i], ENC[i].cout, s));
     }
     return 0;
@@ -143,6 +153,7 @@ int adain_decoder_pack(const float* const* w, const float* const* b, float* pack
     for (int i = 0; i < 8; ++i) {
         RET_IF(launch_pack_conv3x3(w[i], packed + f.w[i], DEC[i].cin, DEC[i].cout, s));
         RET_IF(launch_pack_wino(w[i], packed + f.ww[i], DEC[i].cin, DEC[i].cout, s));
+        RET_IF(launch_pack_wino4(w[i], packed + f.w4[i], DEC[i].cin, DEC[i].cout, s));
         RET_IF(copy_bias(b[i], packed + f.b[i], DEC[i].cout, s));
     }
     RET_IF(launch_pack_conv_last(w[8], packed + f.last_w, s));
@@ -343,9 +354,22 @@ int adain_conv3x3_wino_pack(const float* w, float* packed, int cin, int cout, ad
     return launch_pack_wino(w, packed, cin, cout, (hipStream_t)stream);
 }
 
+size_t adain_conv3x3_wino4_packed_floats(int cin, int cout) { return (size_t)cin * cout * 24; }
+
+int adain_conv3x3_wino4_pack(const float* w, float* packed, int cin, int cout, adain_stream_t stream) {
+    if (!w || !packed) { set_error("conv3x3_wino4_pack: null pointer"); return ADAIN_EINVAL; }
+    return launch_pack_wino4(w, packed, cin, cout, (hipStream_t)stream);
+}
+
 int adain_conv3x3_wino(const float* in, float* out, const float* packed_w, const float* bias, int n, int h, int w, int hs, int ws,
                        int cin, int cout, int src_mode, int relu, int pool_out, int mh, adain_stream_t stream) {
     if (!in || !out || !packed_w || !bias) { set_error("conv3x3_wino: null pointer"); return ADAIN_EINVAL; }
+    if (mh == 5) {      // F(4,3) x F(2,3): weights packed by adain_conv3x3_wino4_pack
+        ConvArgs a5{};
+        a5.in = in; a5.out = out; a5.wpk = packed_w; a5.bias = bias;
+        a5.n = n; a5.H = h; a5.W = w; a5.Hs = hs; a5.Ws = ws; a5.cin = cin; a5.cout = cout; a5.relu = relu; a5.pool_out = pool_out ? 1 : 0;
+        return launch_conv3x3_wino4(a5, src_mode, (hipStream_t)stream);
+    }
     ConvArgs a{};
     a.dbg = (mh >= 13 && mh <= 17) ? g_conv_dbg : nullptr;
     a.in = in; a.out = out; a.wpk = packed_w; a.bias = bias;

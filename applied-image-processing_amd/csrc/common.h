@@ -42,6 +42,9 @@ int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s);
 // conv_wino.hip
 int launch_pack_wino(const float* w_oihw, float* packed, int cin, int cout, hipStream_t s);
 int launch_conv3x3_wino(const ConvArgs& a, int src_mode, int mh, hipStream_t s);   // mh: kernel form (1, 2: V image in LDS; 3: register A; 4: persistent)
+// conv_wino4.hip: F(4,3) x F(2,3) form (its own packed-weight layout, 24 floats per weight pair)
+int launch_pack_wino4(const float* w_oihw, float* packed, int cin, int cout, hipStream_t s);
+int launch_conv3x3_wino4(const ConvArgs& a, int src_mode, hipStream_t s);
 // conv_wino3.hip
 int launch_conv3x3_wino3(const ConvArgs& a, int src_mode, hipStream_t s);
 int launch_conv_first(const float* img_nchw, float* out_nhwc, const float* packed, const float* bias, int n, int H,

@@ -1,0 +1,375 @@
+// Winograd F(4,3) x F(2,3) form of the 3x3 convolution, gfx950: 4 x 2 output tiles (4 rows, 2 columns) from 6 x 4 input
+// patches, 24 multiplies per (cin, cout) pair and tile = 3 per output instead of 4 for F(2x2,3x3) and 9 for the direct form.
+//
+//   Y = A4^T [ sum_cin (G4 g G2^T) .* (B4^T d B2) ] A2          (rows: F(4,3), points 0, +-1, +-2, inf; columns: F(2,3))
+//
+// fp32 error of one layer ~ 1.2e-6 relative (F(2x2,3x3): 4.6e-7, direct: 2.3e-7), far inside the path's tolerance.
+// F(4,3) is applied along the ROWS so that neighbouring lanes' patches stay 2 pixels apart in the LDS halo image (the
+// conflict pattern of the F(2x2,3x3) kernels; 4 pixels apart would be a 4-way conflict for every 16-byte-aligned pixel stride).
+//
+// Mapping (conv3x3_wino2_kernel's, with the roles of rows and columns swapped):
+//   * block = 4 waves, tile = 32 Winograd tiles (2 tile rows x 16 tile columns = 8 x 32 output pixels) x 32 channels;
+//   * the 24 transform positions xi = (r, j) are 24 GEMMs [32 tiles x cin] x [cin x 32]; wave j owns transform COLUMN j
+//     (its 6 row positions r): 6 MFMA tiles of 32x32 = 96 accumulator registers (v_mfma_f32_32x32x2_f32, A = weights,
+//     B = tiles, so that a lane holds 4 consecutive channels of one tile);
+//   * A-side operand in registers: column j of d B2 needs two patch columns, so a lane reads 6 rows x 2 columns (b128,
+//     4 channels) from the raw reflect-padded 10 x 34 halo image in LDS, combines them (24 adds) and applies B4^T down the
+//     rows (48 fma/adds); fragments are updated in place (row r's fragment is dead once step r has issued);
+//   * weights U = G4 g G2^T packed once as [cout/32][j][cin/8][r][lane][4], streamed into a 6-slot register ring (slot = r);
+//   * the raw halo is staged 16 channels at a time (global -> registers -> LDS), one barrier per 48 MFMAs per wave;
+//   * epilogue: P_j = A4^T M_j per wave (4 values), the four columns meet in LDS (64 KiB, XOR-swizzled b128), then
+//     Y = P A2: bias, ReLU, optional 2x2 max-pool (a tile holds two pool windows), b128 buffer stores.
+#include <stdlib.h>
+#include <type_traits>
+
+#include "common.h"
+#include "device_utils.h"
+
+namespace adain {
+
+namespace {
+constexpr int W4_KR = 16;                    // channels per raw stage = 2 chunks of 8
+constexpr int W4_RSTR = W4_KR + 4;           // floats per halo pixel (80 B)
+constexpr int W4_HALO_W = 34, W4_HALO_H = 10;
+constexpr int W4_HALO = W4_HALO_H * W4_HALO_W;        // 340 pixels
+constexpr int W4_RITEMS = 6;                           // 340 x 4 quads over 256 threads
+constexpr int W4_RBUF = W4_RITEMS * 64 * W4_RSTR;      // rounded up to the staging items: 384 pixels
+constexpr int W4_PEX = 4 * 4 * 32 * 32;                // [column j][a][tile][32 channels] floats = 64 KiB
+static_assert(W4_HALO * 4 <= W4_RITEMS * 256, "staging items");
+static_assert(2 * W4_RBUF <= W4_PEX, "LDS layout");
+
+// literal scalar offset only: see conv_wino3.hip (gfx950 b128 buffer-store hazard)
+__device__ __forceinline__ void buf_store4(rsrc_t r, f32x4 v, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+}  // namespace
+
+// OIHW [cout][cin][3][3] -> U = G4 g G2^T packed as [cout/32][j 4][cin/8][r 6][lane 64][s 4]:
+//   value = U[r][j][cout = 32 ct + (lane & 31)][cin = 8 chunk + 4 (lane >> 5) + s]
+__global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict__ p, int cin, int cout) {
+    const float G2[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    const float G4[6][3] = {{0.25f, 0.f, 0.f},           {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                            {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    const size_t total = (size_t)cin * cout * 24;
+    const int nch = cin / 8;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t t = idx;
+        const int s = t & 3; t >>= 2;
+        const int lane = t & 63; t >>= 6;
+        const int r = t % 6; t /= 6;
+        const int chunk = t % nch; t /= nch;
+        const int j = t & 3; t >>= 2;
+        const int ct = (int)t;
+        const int co = ct * 32 + (lane & 31), ci = chunk * 8 + 4 * (lane >> 5) + s;
+        const float* g = w + ((size_t)co * cin + ci) * 9;
+        float u = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) u += G4[r][a] * g[a * 3 + b] * G2[j][b];
+        p[idx] = u;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[W4_PEX];
+    float* const Rs = smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wj = __builtin_amdgcn_readfirstlane(tid >> 6);      // transform column of this wave
+    // the one lane constant kept live through the main loop; other lane-derived addresses are rebuilt from an opaque copy
+    const int wvo = lane * 16;
+    auto lane_now = [&]() {
+        int w = wvo;
+        asm volatile("" : "+v"(w));
+        return w >> 4;
+    };
+
+    // block -> (channel tile fastest, pixel tile, image) inside a contiguous per-XCD range (halo reuse in L2)
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int nct = a.cout / 32;
+    int lid = blockIdx.x;
+    if (a.xcd_order && (gridDim.x & 7) == 0) lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
+    const int ct = lid % nct; lid /= nct;
+    const int pt = lid % tiles;
+    const int img = lid / tiles;
+    const int tx0 = (pt % a.tiles_x) * 32, ty0 = (pt / a.tiles_x) * 8;
+    const int nst = a.cin / W4_KR;
+    const int nch = a.cin / 8;
+
+    const rsrc_t src = make_rsrc(a.in + (size_t)img * a.Hs * a.Ws * a.cin, (unsigned)a.Hs * a.Ws * a.cin * 4u);
+    const rsrc_t wsr = make_rsrc(a.wpk, (unsigned)a.cin * a.cout * 96u);
+
+    // ---- raw halo staging: 340 pixels x 4 quads over 256 threads x 6 items ---------------------------------------------------
+    int roff[W4_RITEMS];
+#pragma unroll
+    for (int k = 0; k < W4_RITEMS; ++k) {
+        const int idx = tid + k * 256;
+        const int hp = min(idx >> 2, W4_HALO - 1), q = idx & 3;
+        const int hy = hp / W4_HALO_W, hx = hp - hy * W4_HALO_W;
+        int y = reflect1(ty0 + hy - 1, a.H), x = reflect1(tx0 + hx - 1, a.W);
+        if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
+        roff[k] = ((y * a.Ws + x) * a.cin + q * 4) * 4;
+    }
+    f32x4 rawreg[W4_RITEMS];
+    auto raw_load = [&](int soff) {
+#pragma unroll
+        for (int k = 0; k < W4_RITEMS; ++k) rawreg[k] = buf_load4(src, roff[k], soff);
+    };
+    auto raw_store = [&](float* buf) {
+        const int t = lane_now() | (wj << 6);
+        const int st_base = (t >> 2) * W4_RSTR + (t & 3) * 4;      // item k: pixel (t >> 2) + 64 k -> one address + immediates
+#pragma unroll
+        for (int k = 0; k < W4_RITEMS; ++k) *(f32x4*)(buf + st_base + k * 64 * W4_RSTR) = rawreg[k];   // items past the halo: unused tail
+    };
+
+    // ---- weights: one b128 fragment per step (row position r), ring slot = r, loaded 5 steps ahead ---------------------------
+    f32x4 bq[6];
+    int wso = ((ct * 4 + wj) * nch) * 6144;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) bq[r] = buf_load4(wsr, wvo, wso + r * 1024);
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+    // the main loop is instantiated once per transform column (WJ compile-time): see conv_wino.hip
+    auto main_loop = [&](auto WJC) {
+        constexpr int WJ = decltype(WJC)::value;
+        constexpr int cA = WJ == 0 ? 0 : 1, cB = WJ == 3 ? 3 : 2;
+        asm volatile("; transform column %0" ::"n"(WJ));
+        // patch rows 0-2, then 3-5: column combine f[a] = d[a][cA] +- d[a][cB]
+        f32x4 dA[3], dB[3], f[6], o4, o5;
+        auto xf_read = [&](const float* rb, int a0) {
+            const int l = lane_now(), li = l & 31, lh = l >> 5;
+            const int p_base = ((4 * (li >> 4)) * W4_HALO_W + 2 * (li & 15)) * W4_RSTR + 4 * lh;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dA[k] = *(const f32x4*)(rb + p_base + ((a0 + k) * W4_HALO_W + cA) * W4_RSTR);
+                dB[k] = *(const f32x4*)(rb + p_base + ((a0 + k) * W4_HALO_W + cB) * W4_RSTR);
+            }
+        };
+        auto xf_cols = [&](int a0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if constexpr (WJ == 1) f[a0 + k] = dA[k] + dB[k];
+                else if constexpr (WJ == 2) f[a0 + k] = dB[k] - dA[k];
+                else f[a0 + k] = dA[k] - dB[k];
+            }
+        };
+        // B4^T down the rows: (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1)
+        auto rows_012 = [&](f32x4 (&q)[6]) {
+            q[0] = 4.f * f[0] + (f[4] - 5.f * f[2]);
+            const f32x4 t1 = f[4] - 4.f * f[2], t2 = f[3] - 4.f * f[1];
+            q[1] = t1 + t2;
+            q[2] = t1 - t2;
+        };
+        auto rows_34 = [&](f32x4 (&q)[6]) {
+            const f32x4 t3 = f[4] - f[2], d31 = f[3] - f[1];
+            q[3] = t3 + 2.f * d31;
+            o4 = t3 - 2.f * d31;
+        };
+        auto rows_5 = [&]() { o5 = 4.f * f[1] + (f[5] - 5.f * f[3]); };
+
+        f32x4 aq[6];
+        // one chunk of 8 channels = 6 steps (row positions) of 4 MFMAs.  XF: transform the next chunk's patches meanwhile;
+        // ST: the last step also writes the staged halo registers to LDS; LD: the first steps also issue the halo loads
+        auto chunk = [&](const float* nsrc, auto XFC, auto STC, auto LDC, int raw_soff, float* store_to) {
+            constexpr bool do_xf = decltype(XFC)::value, st = decltype(STC)::value, ld = decltype(LDC)::value;
+            auto step = [&](auto RR) {
+                constexpr int r = decltype(RR)::value;
+                // slot r - 1 was consumed by the previous step: refill it with the next chunk's fragment; slot 5 is refilled
+                // with THIS chunk's last fragment at step 0 (its previous content was consumed at the end of the last chunk)
+                if constexpr (r == 0) bq[5] = buf_load4(wsr, wvo, wso + 5 * 1024);
+                else bq[r - 1] = buf_load4(wsr, wvo, wso + 6144 + (r - 1) * 1024);
+                if constexpr (ld && r == 0) raw_load(raw_soff);
+                if constexpr (st && r == 5) raw_store(store_to);
+                if constexpr (do_xf) {
+                    if constexpr (r == 0) xf_read(nsrc, 0);
+                    if constexpr (r == 1) { xf_cols(0); xf_read(nsrc, 3); }
+                    if constexpr (r == 2) xf_cols(3);
+                    if constexpr (r == 3) rows_012(aq);          // fragments 0..2 are dead: steps 0..2 have issued
+                    if constexpr (r == 4) rows_34(aq);           // fragment 3 is dead
+                    if constexpr (r == 5) { aq[4] = o4; rows_5(); }
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[r][s], aq[r][s], acc[r], 0, 0, 0);
+                if constexpr (do_xf && r == 5) aq[5] = o5;
+                // issue order: one MFMA, then one slice of the step's other work in its shadow
+#define W4_MFMA __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#define W4_VMEM __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#define W4_DSRD(n) if constexpr (do_xf && (r == 0 || r == 1)) __builtin_amdgcn_sched_group_barrier(0x100, n, 0);
+#define W4_VALU(n) if constexpr (do_xf && r >= 1) __builtin_amdgcn_sched_group_barrier(0x002, n, 0);
+#define W4_HALO_LD(n) if constexpr (ld && r == 0) __builtin_amdgcn_sched_group_barrier(0x020, n, 0);
+#define W4_HALO_ST(n)                                                                                     \
+                if constexpr (st && r == 5) {                                                             \
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+                    __builtin_amdgcn_sched_group_barrier(0x200, n, 0);                                    \
+                }
+                W4_MFMA W4_VMEM W4_DSRD(2) W4_VALU(6) W4_HALO_ST(2)
+                W4_MFMA W4_DSRD(2) W4_VALU(6) W4_HALO_LD(2) W4_HALO_ST(2)
+                W4_MFMA W4_DSRD(1) W4_VALU(6) W4_HALO_LD(2) W4_HALO_ST(1)
+                W4_MFMA W4_DSRD(1) W4_VALU(6) W4_HALO_LD(2) W4_HALO_ST(1)
+#undef W4_MFMA
+#undef W4_VMEM
+#undef W4_DSRD
+#undef W4_VALU
+#undef W4_HALO_LD
+#undef W4_HALO_ST
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{});
+            step(std::integral_constant<int, 5>{});
+            wso += 6144;
+        };
+        constexpr std::true_type T{};
+        constexpr std::false_type F{};
+
+        // ---- prologue --------------------------------------------------------------------------------------------------------------
+        raw_load(0);
+        raw_store(Rs);
+        __syncthreads();
+        raw_load(W4_KR * 4);                                // stages past the end read neighbouring data or zeros, never consumed
+        xf_read(Rs, 0); xf_cols(0);
+        xf_read(Rs, 3); xf_cols(3);
+        rows_012(aq); rows_34(aq); rows_5();
+        aq[4] = o4; aq[5] = o5;
+
+        for (int s = 0; s + 1 < nst; ++s) {
+            const float* cur = Rs + (s & 1) * W4_RBUF;
+            float* nxt = Rs + ((s + 1) & 1) * W4_RBUF;
+            chunk(cur + 8, T, T, F, 0, nxt);                // channels 0..7; prepares 8..15; writes the next stage's halo
+            __syncthreads();
+            chunk(nxt, T, F, T, (s + 2) * W4_KR * 4, nullptr);      // channels 8..15; prepares the next stage; loads two stages ahead
+        }
+        chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr);
+        chunk(Rs, F, F, F, 0, nullptr);
+    };
+    if (wj == 0) main_loop(std::integral_constant<int, 0>{});
+    else if (wj == 1) main_loop(std::integral_constant<int, 1>{});
+    else if (wj == 2) main_loop(std::integral_constant<int, 2>{});
+    else main_loop(std::integral_constant<int, 3>{});
+    __syncthreads();
+
+    // ---- epilogue -------------------------------------------------------------------------------------------------------------------
+    // lane (li = tile, lh): acc[r][e16] = M[row r][column wj][channel 8 (e16 >> 2) + 4 lh + (e16 & 3)][tile li]
+    {
+        const int le = lane_now(), li = le & 31, lh = le >> 5;
+        float* Pw = smem + (wj * 4) * (32 * 32) + li * 32;
+        const int sw = (li >> 1) & 7;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            f32x4 P0, P1, P2, P3;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = rq * 4 + e;
+                const float s1 = acc[1][k] + acc[2][k], d1 = acc[1][k] - acc[2][k];
+                const float s2 = acc[3][k] + acc[4][k], d2 = acc[3][k] - acc[4][k];
+                P0[e] = acc[0][k] + s1 + s2;               // A4^T = (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,0) (0,1,-1,8,-8,1)
+                P1[e] = d1 + 2.f * d2;
+                P2[e] = s1 + 4.f * s2;
+                P3[e] = d1 + 8.f * d2 + acc[5][k];
+            }
+            const int slot = ((2 * rq + lh) ^ sw) << 2;    // channel quad of the 32, XOR-swizzled: conflict-free both ways
+            *(f32x4*)(Pw + slot) = P0;
+            *(f32x4*)(Pw + 1 * 32 * 32 + slot) = P1;
+            *(f32x4*)(Pw + 2 * 32 * 32 + slot) = P2;
+            *(f32x4*)(Pw + 3 * 32 * 32 + slot) = P3;
+        }
+    }
+    __syncthreads();
+    {
+        const int le = lane_now(), q8 = le & 7, tt = le >> 3;
+        const int tl = wj * 8 + tt;
+        const float* Pr = smem + tl * 32 + ((q8 ^ ((tl >> 1) & 7)) << 2);
+        const f32x4 bias4 = *(const f32x4*)(a.bias + ct * 32 + 4 * q8);
+        const int Ho = a.pool_out ? (a.H + 1) >> 1 : a.H, Wo = a.pool_out ? (a.W + 1) >> 1 : a.W;
+        const rsrc_t dst = make_rsrc(a.out + (size_t)img * Ho * Wo * a.cout, (unsigned)(Ho * Wo * a.cout) * 4u);
+        const int oy = ty0 + 4 * (tl >> 4), ox = tx0 + 2 * (tl & 15);
+        const int cbyte = (ct * 32 + 4 * q8) * 4;
+        const bool colok0 = ox < a.W, colok1 = ox + 1 < a.W;
+        f32x4 y[4][2];
+#pragma unroll
+        for (int ap = 0; ap < 4; ++ap) {
+            f32x4 P[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) P[j] = *(const f32x4*)(Pr + (j * 4 + ap) * (32 * 32));
+            y[ap][0] = P[0] + P[1] + P[2] + bias4;          // A2 = columns (1,1,1,0), (0,1,-1,-1)
+            y[ap][1] = P[1] - P[2] - P[3] + bias4;
+            if (a.relu) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                y[ap][0] = max4(y[ap][0], z);
+                y[ap][1] = max4(y[ap][1], z);
+            }
+        }
+        if (a.pool_out) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {               // two pool windows per tile: rows (0,1) and (2,3)
+                const int r0 = oy + 2 * h2;
+                f32x4 v = y[2 * h2][0];
+                if (colok1) v = max4(v, y[2 * h2][1]);
+                if (r0 + 1 < a.H) {
+                    v = max4(v, y[2 * h2 + 1][0]);
+                    if (colok1) v = max4(v, y[2 * h2 + 1][1]);
+                }
+                const int off = (((r0 >> 1) * Wo + (ox >> 1)) * a.cout) * 4 + cbyte;
+                buf_store4(dst, v, (r0 < a.H && colok0) ? off : 0x7fffffff);
+            }
+        } else {
+#pragma unroll
+            for (int ap = 0; ap < 4; ++ap) {
+                const int off = (((oy + ap) * a.W + ox) * a.cout) * 4 + cbyte;
+                const bool rowok = oy + ap < a.H;
+                buf_store4(dst, y[ap][0], (rowok && colok0) ? off : 0x7fffffff);
+                buf_store4(dst, y[ap][1], (rowok && colok1) ? off + a.cout * 4 : 0x7fffffff);
+            }
+        }
+    }
+}
+
+int launch_pack_wino4(const float* w, float* p, int cin, int cout, hipStream_t s) {
+    if (cin % 8 || cout % 32) { set_error("pack_wino4: cin %% 8 or cout %% 32 != 0 (%d, %d)", cin, cout); return -1; }
+    const size_t total = (size_t)cin * cout * 24;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_wino4_kernel, dim3(blocks), dim3(256), 0, s, w, p, cin, cout);
+    return check_launch("pack_wino4");
+}
+
+int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
+    ConvArgs a = a0;
+    if (a.cin % W4_KR || a.cin < W4_KR) { set_error("conv3x3_wino4: cin %d not a multiple of 16", a.cin); return -1; }
+    if (a.cout % 32) { set_error("conv3x3_wino4: cout %d not a multiple of 32", a.cout); return -1; }
+    if (a.H < 2 || a.W < 2 || a.n < 1) { set_error("conv3x3_wino4: H, W must be >= 2, got %dx%d", a.H, a.W); return -1; }
+    if ((size_t)a.Hs * a.Ws * a.cin * 4 >= 0x7fffffffULL || (size_t)a.H * a.W * a.cout * 4 >= 0x7fffffffULL) {
+        set_error("conv3x3_wino4: per-image tensors must stay below 2 GiB");
+        return -1;
+    }
+    if ((size_t)a.cin * a.cout * 96 >= 0xffffffffULL) { set_error("conv3x3_wino4: packed weights must stay below 4 GiB"); return -1; }
+    if (src_mode == SRC_DIRECT) {
+        if (a.Hs != a.H || a.Ws != a.W) { set_error("conv3x3_wino4: direct mode needs Hs==H, Ws==W"); return -1; }
+    } else if (src_mode == SRC_UP2X) {
+        if (a.H != 2 * a.Hs || a.W != 2 * a.Ws) { set_error("conv3x3_wino4: up2x mode needs H==2Hs, W==2Ws"); return -1; }
+    } else {
+        set_error("conv3x3_wino4: unsupported src_mode %d", src_mode);
+        return -1;
+    }
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + 7) / 8;
+    const long long blocks = (long long)a.tiles_x * a.tiles_y * (a.cout / 32) * a.n;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv3x3_wino4: bad grid %lld", blocks); return -1; }
+    a.xcd_order = 1;
+    const dim3 g((unsigned)blocks);
+    if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X>), g, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a);
+    return check_launch("conv3x3_wino4");
+}
+
+}  // namespace adain

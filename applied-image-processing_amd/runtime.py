@@ -52,6 +52,8 @@ SIGNATURES = {
     "adain_conv3x3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 11 + [_c_void_p]),
     "adain_conv3x3_wino_packed_floats": (_c_size_t, [_c_int, _c_int]),
     "adain_conv3x3_wino_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
+    "adain_conv3x3_wino4_packed_floats": (_c_size_t, [_c_int, _c_int]),
+    "adain_conv3x3_wino4_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
     "adain_conv3x3_wino": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 11 + [_c_void_p]),
 }
 
@@ -373,12 +375,15 @@ def conv3x3(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, pool_o
     return out
 
 
-def conv3x3_wino_pack(w_oihw):
+def conv3x3_wino_pack(w_oihw, form=3):
+    """Packed transformed weights for conv3x3_wino; form 5 (F(4,3) x F(2,3)) has its own layout."""
     w = _dev(w_oihw, "weight")
     cout, cin = w.shape[:2]
-    packed = torch.empty(lib().adain_conv3x3_wino_packed_floats(cin, cout), dtype=torch.float32, device=w.device)
+    sizer, packer = ((lib().adain_conv3x3_wino4_packed_floats, lib().adain_conv3x3_wino4_pack) if form == 5 else
+                     (lib().adain_conv3x3_wino_packed_floats, lib().adain_conv3x3_wino_pack))
+    packed = torch.empty(sizer(cin, cout), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
-        _check(lib().adain_conv3x3_wino_pack(w.data_ptr(), packed.data_ptr(), cin, cout, _stream()), "adain_conv3x3_wino_pack")
+        _check(packer(w.data_ptr(), packed.data_ptr(), cin, cout, _stream()), "adain_conv3x3_wino_pack")
     return packed
 
 

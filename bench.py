@@ -38,6 +38,12 @@ import applied_image_processing_amd.synth as synth
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)"
 WINOGRAD = os.environ.get("ADAIN_WINOGRAD", "1") != "0"      # the C library's default; ADAIN_WINOGRAD=0 = direct implicit GEMM
+WINO_FORM = int(os.environ.get("ADAIN_WINO_MH", "5"))          # the C library's default: 5 = F(4,3) x F(2,3); others F(2x2,3x3)
+# multiplies the conv3x3 kernel executes on the matrix pipe per direct-convolution multiply
+EXECUTED = (24.0 / 72.0 if WINO_FORM == 5 else 16.0 / 36.0) if WINOGRAD else 1.0
+CONV_KERNEL = ("conv3x3_mfma_kernel / conv3x3_persist_kernel" if not WINOGRAD else
+               "conv3x3_wino4_kernel (Winograd F(4,3) x F(2,3))" if WINO_FORM == 5 else
+               "conv3x3_wino2_kernel + conv3x3_wino3_kernel (Winograd F(2x2,3x3))")
 WORKLOADS = {
     2: "configs[1]: {h}x{w} AdaIN forward (style_transfer_simple), batch={b} per GPU, style {hs}x{ws} re-encoded every step, alpha=0.5",
     3: "configs[2]: {h}x{w} depth-aware AdaIN (style_transfer, proximity-map blend), batch={b} per GPU, style {hs}x{ws} re-encoded every step",
@@ -213,12 +219,13 @@ def measure_roofline(step, reps):
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
         "traffic": load_pmc_traffic(f"config{step.config}_batch{step.batch}"),
-        "kernel": ("conv3x3_wino2_kernel + conv3x3_wino3_kernel (Winograd F(2x2,3x3))" if WINOGRAD else "conv3x3_mfma_kernel / conv3x3_persist_kernel") + f" ({len(flops)} launches/step)",
+        "kernel": CONV_KERNEL + f" ({len(flops)} launches/step)",
         "avg_launch_ms": round(avg_ms, 4), "flop_per_launch_avg": sum(flops) / len(flops),
-        # `achieved` counts the ALGORITHMIC flops of the direct 3x3 convolution.  The Winograd F(2x2,3x3)
-        # kernel executes 16/36 of those multiplies on the matrix pipe, which is how `frac` can exceed 1.
-        "executed_mfma_tflops": round(achieved * (16.0 / 36.0 if WINOGRAD else 1.0), 2),
-        "executed_mfma_frac": round(achieved * (16.0 / 36.0 if WINOGRAD else 1.0) / PEAK_FP32_MFMA_TFLOPS, 4),
+        # `achieved` counts the ALGORITHMIC flops of the direct 3x3 convolution.  The Winograd kernels execute
+        # 24/72 (F(4,3) x F(2,3): 24 multiplies per 4 x 2 outputs) or 16/36 (F(2x2,3x3)) of those multiplies on the matrix
+        # pipe, which is how `frac` can exceed 1.
+        "executed_mfma_tflops": round(achieved * EXECUTED, 2),
+        "executed_mfma_frac": round(achieved * EXECUTED / PEAK_FP32_MFMA_TFLOPS, 4),
         "algorithmic_bytes_per_launch_avg": sum(step.conv3x3_algorithmic_bytes()) / len(flops),
     }, layers
 

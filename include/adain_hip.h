@@ -136,6 +136,9 @@ int adain_conv3x3(const float* in_nhwc, float* out_nhwc, const float* packed_w, 
  * (cin, cout) pair).  src_mode DIRECT or UP2X; cin % 8 == 0, cout % 64 == 0. */
 size_t adain_conv3x3_wino_packed_floats(int cin, int cout);
 int adain_conv3x3_wino_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
+/* F(4,3) x F(2,3) form (form = 5 of adain_conv3x3_wino): its own packed layout, 24 floats per (cin, cout) pair */
+size_t adain_conv3x3_wino4_packed_floats(int cin, int cout);
+int adain_conv3x3_wino4_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
 int adain_conv3x3_wino(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,
                        int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out,
                        int form /* 3: A operand transformed in registers (default of encode/decode; cin % 16 == 0); 1 / 2: transformed

@@ -105,7 +105,7 @@ def test_conv3x3_tile_variants_and_fused_output_pool(rt, variant, shape):
             rt.conv3x3(xg, packed, b.cuda(), cout, rt.SRC_DIRECT, relu=True, pool_out=True, variant=variant)
 
 
-@pytest.mark.parametrize("m_tiles", [2, 1, 3, 4])
+@pytest.mark.parametrize("m_tiles", [2, 1, 3, 4, 5])
 @pytest.mark.parametrize("mode", ["direct", "up"])
 @pytest.mark.parametrize("shape", [(1, 128, 128, 16, 32), (2, 128, 64, 9, 37), (1, 256, 128, 21, 70), (1, 512, 256, 5, 6), (1, 64, 64, 8, 8)])
 def test_conv3x3_winograd_vs_oracle(rt, mode, shape, m_tiles):
@@ -117,7 +117,7 @@ def test_conv3x3_winograd_vs_oracle(rt, mode, shape, m_tiles):
     src = F.interpolate(x, scale_factor=2, mode="nearest") if mode == "up" else x
     pre = F.conv2d(F.pad(src, (1, 1, 1, 1), mode="reflect"), w, b)
     xg = x.cuda().permute(0, 2, 3, 1).contiguous()
-    packed = rt.conv3x3_wino_pack(w.cuda())
+    packed = rt.conv3x3_wino_pack(w.cuda(), m_tiles)
     m = rt.SRC_UP2X if mode == "up" else rt.SRC_DIRECT
     close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True, m_tiles=m_tiles).permute(0, 3, 1, 2), F.relu(pre))
     close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=False, m_tiles=m_tiles).permute(0, 3, 1, 2), pre)

@@ -55,12 +55,15 @@ def main():
         b = torch.zeros(cout, device=dev)
         packed = rt.conv3x3_pack(w)
         wino = rt.conv3x3_wino_pack(w) if cin % 8 == 0 and mode != rt.SRC_POOL2 else None
+        wino4 = rt.conv3x3_wino_pack(w, 5) if 24 in variants else None
 
         def run(v):
-            if v in (20, 21, 22, 23):      # Winograd F(2x2,3x3): 20 = 8 waves (2 M-tiles), 21 = 4 waves (1 M-tile)
+            if v in (20, 21, 22, 23, 24):      # Winograd F(2x2,3x3): 20 = 8 waves (2 M-tiles), 21 = 4 waves (1 M-tile)
                 if wino is None:
                     raise rt.AdainHipError("no winograd form")
-                return rt.conv3x3_wino(x, wino, b, cout, mode, True, pool, {20: 2, 21: 1, 22: 3, 23: 4}[v])
+                if v == 24:
+                    return rt.conv3x3_wino(x, wino4, b, cout, mode, True, pool, 5)
+                return rt.conv3x3_wino(x, wino, b, cout, mode, True, pool, {20: 2, 21: 1, 22: 3, 23: 4, 24: 5}[v])
             return rt.conv3x3(x, packed, b, cout, mode, True, pool, v)
 
         flops = 2.0 * h * h * cin * cout * 9
