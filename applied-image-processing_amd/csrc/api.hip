@@ -367,6 +367,7 @@ int adain_conv3x3_wino(const float* in, float* out, const float* packed_w, const
     if (mh == 5) {      // F(4,3) x F(2,3): weights packed by adain_conv3x3_wino4_pack
         ConvArgs a5{};
         a5.in = in; a5.out = out; a5.wpk = packed_w; a5.bias = bias;
+        a5.dbg = g_conv_dbg;     // diagnostic builds only (tools/wino4_probe.py sets it)
         a5.n = n; a5.H = h; a5.W = w; a5.Hs = hs; a5.Ws = ws; a5.cin = cin; a5.cout = cout; a5.relu = relu; a5.pool_out = pool_out ? 1 : 0;
         return launch_conv3x3_wino4(a5, src_mode, (hipStream_t)stream);
     }

@@ -21,6 +21,7 @@
 //     Y = P A2: bias, ReLU, optional 2x2 max-pool (a tile holds two pool windows), b128 buffer stores.
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "device_utils.h"
@@ -71,10 +72,14 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
-template <int MODE>
+// DIAG (tools/wino4_probe.py, not the product path): 1 = a shader-clock stamp per 8-MFMA double step of the first 32 workgroups,
+// 2 = the same with LDS padded to one workgroup per CU
+template <int MODE, int DIAG = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[W4_PEX];
+    __shared__ __attribute__((aligned(16))) float smem[DIAG >= 2 ? W4_PEX + 8192 : (DIAG == 1 ? W4_PEX + 1024 : W4_PEX)];
     float* const Rs = smem;
+    unsigned* const steplog = (unsigned*)(smem + W4_PEX);     // DIAG: [wave][96] low words of s_memtime
+    int nlog = 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
         const int idx = tid + k * 256;
         const int hp = min(idx >> 2, W4_HALO - 1), q = idx & 3;
         const int hy = hp / W4_HALO_W, hx = hp - hy * W4_HALO_W;
-        int y = reflect1(ty0 + hy - 1, a.H), x = reflect1(tx0 + hx - 1, a.W);
+        int y = reflect1((DIAG == 3 ? 0 : ty0) + hy - 1, a.H), x = reflect1((DIAG == 3 ? 0 : tx0) + hx - 1, a.W);   // DIAG 3: timing-only, every halo from L2
         if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
         roff[k] = ((y * a.Ws + x) * a.cin + q * 4) * 4;
     }
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
     f32x4 bq[6];
     int wso = ((ct * 4 + wj) * nch) * 6144;
 #pragma unroll
-    for (int r = 0; r < 5; ++r) bq[r] = buf_load4(wsr, wvo, wso + r * 1024);
+    for (int r = 0; r < 4; ++r) bq[r] = buf_load4(wsr, wvo, wso + r * 1024);
 
     f32x16 acc[6];
 #pragma unroll
@@ -144,15 +149,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
         asm volatile("; transform column %0" ::"n"(WJ));
         // patch rows 0-2, then 3-5: column combine f[a] = d[a][cA] +- d[a][cB]
         f32x4 dA[3], dB[3], f[6], o4, o5;
-        auto xf_read = [&](const float* rb, int a0) {
-            const int l = lane_now(), li = l & 31, lh = l >> 5;
-            const int p_base = ((4 * (li >> 4)) * W4_HALO_W + 2 * (li & 15)) * W4_RSTR + 4 * lh;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                dA[k] = *(const f32x4*)(rb + p_base + ((a0 + k) * W4_HALO_W + cA) * W4_RSTR);
-                dB[k] = *(const f32x4*)(rb + p_base + ((a0 + k) * W4_HALO_W + cB) * W4_RSTR);
-            }
-        };
         auto xf_cols = [&](int a0) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -175,59 +171,80 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
         };
         auto rows_5 = [&]() { o5 = 4.f * f[1] + (f[5] - 5.f * f[3]); };
 
-        f32x4 aq[6];
-        // one chunk of 8 channels = 6 steps (row positions) of 4 MFMAs.  XF: transform the next chunk's patches meanwhile;
-        // ST: the last step also writes the staged halo registers to LDS; LD: the first steps also issue the halo loads
+        f32x4 aq[6], q2, q3, t1, t2, t3, d31;
+        int xaddr = 0;          // this lane's patch origin in the halo image (floats), rebuilt at the start of every chunk
+        auto xf_addr = [&]() {
+            const int l = lane_now(), li = l & 31, lh = l >> 5;
+            xaddr = ((4 * (li >> 4)) * W4_HALO_W + 2 * (li & 15)) * W4_RSTR + 4 * lh;
+        };
+        auto xf_read3 = [&](const float* rb, int a0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dA[k] = *(const f32x4*)(rb + xaddr + ((a0 + k) * W4_HALO_W + cA) * W4_RSTR);
+                dB[k] = *(const f32x4*)(rb + xaddr + ((a0 + k) * W4_HALO_W + cB) * W4_RSTR);
+            }
+        };
+        int saddr = 0;
+        auto st_addr = [&]() {
+            const int t = lane_now() | (wj << 6);
+            saddr = (t >> 2) * W4_RSTR + (t & 3) * 4;              // item k: pixel (t >> 2) + 64 k -> one address + immediates
+        };
+        // One chunk of 8 channels = 24 MFMAs in 24 scheduling regions of ONE MFMA plus its share of the chunk's other work
+        // (issued right behind it, in its 64-cycle shadow).  Regions alternate between the accumulators of row positions 2d
+        // and 2d+1 (d = region / 8): four back-to-back MFMAs on one accumulator are a dependent chain (tools/wino4_probe.py:
+        // 412 cycles per 4 instead of 256 + issue overheads), and left to itself the scheduler builds exactly those chains.
+        // XF: transform the next chunk's patches meanwhile; ST: the last third also writes the staged halo registers to LDS;
+        // LD: the halo loads two stages ahead.  Weight ring: slot = row position, refilled as soon as its MFMAs have issued.
         auto chunk = [&](const float* nsrc, auto XFC, auto STC, auto LDC, int raw_soff, float* store_to) {
             constexpr bool do_xf = decltype(XFC)::value, st = decltype(STC)::value, ld = decltype(LDC)::value;
-            auto step = [&](auto RR) {
-                constexpr int r = decltype(RR)::value;
-                // slot r - 1 was consumed by the previous step: refill it with the next chunk's fragment; slot 5 is refilled
-                // with THIS chunk's last fragment at step 0 (its previous content was consumed at the end of the last chunk)
-                if constexpr (r == 0) bq[5] = buf_load4(wsr, wvo, wso + 5 * 1024);
-                else bq[r - 1] = buf_load4(wsr, wvo, wso + 6144 + (r - 1) * 1024);
-                if constexpr (ld && r == 0) raw_load(raw_soff);
-                if constexpr (st && r == 5) raw_store(store_to);
+            auto half = [&](auto HH) {
+                constexpr int h = decltype(HH)::value;          // 0..23: mini-step m = h / 2 (d = m / 4, s = m % 4), b = second MFMA
+                constexpr int m = h / 2, b = h & 1, d = m / 4, sidx = m & 3, r = 2 * d + b;
+                if constexpr (DIAG != 0 && (h % 8) == 0) {
+                    const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
+                    if (lane_now() == 0 && nlog < 96) steplog[WJ * 96 + nlog] = tnow;
+                    ++nlog;
+                }
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[r][sidx], aq[r][sidx], acc[r], 0, 0, 0);
+                // ---- weight ring: (this chunk) slots 4, 5 at mini-steps 0, 1; (next chunk) slots 0, 1 at 4, 5; slots 2, 3 at 8, 9 ----
+                if constexpr (b == 0) {
+                    if constexpr (m == 0) bq[4] = buf_load4(wsr, wvo, wso + 4 * 1024);
+                    if constexpr (m == 1) bq[5] = buf_load4(wsr, wvo, wso + 5 * 1024);
+                    if constexpr (m == 4) bq[0] = buf_load4(wsr, wvo, wso + 6144);
+                    if constexpr (m == 5) bq[1] = buf_load4(wsr, wvo, wso + 6144 + 1024);
+                    if constexpr (m == 8) bq[2] = buf_load4(wsr, wvo, wso + 6144 + 2 * 1024);
+                    if constexpr (m == 9) bq[3] = buf_load4(wsr, wvo, wso + 6144 + 3 * 1024);
+                }
+                // ---- halo loads two stages ahead, in the first two thirds of the chunk (regions 5, 7, 9, 11, 13, 15) ----
+                if constexpr (ld && b == 1 && h >= 5 && h <= 15) {
+                    constexpr int k = (h - 5) / 2;
+                    rawreg[k] = buf_load4(src, roff[k], raw_soff);
+                }
+                // ---- input transform of the next chunk ----
                 if constexpr (do_xf) {
-                    if constexpr (r == 0) xf_read(nsrc, 0);
-                    if constexpr (r == 1) { xf_cols(0); xf_read(nsrc, 3); }
-                    if constexpr (r == 2) xf_cols(3);
-                    if constexpr (r == 3) rows_012(aq);          // fragments 0..2 are dead: steps 0..2 have issued
-                    if constexpr (r == 4) rows_34(aq);           // fragment 3 is dead
-                    if constexpr (r == 5) { aq[4] = o4; rows_5(); }
+                    if constexpr (h == 0) xf_addr();
+                    if constexpr (h == 1) xf_read3(nsrc, 0);
+                    if constexpr (h == 4) xf_cols(0);
+                    if constexpr (h == 5) xf_read3(nsrc, 3);
+                    if constexpr (h == 8) xf_cols(3);
+                    if constexpr (h == 9) aq[0] = 4.f * f[0] + (f[4] - 5.f * f[2]);                 // fragments 0, 1: dead since mini-step 3
+                    if constexpr (h == 10) { t1 = f[4] - 4.f * f[2]; t2 = f[3] - 4.f * f[1]; }
+                    if constexpr (h == 11) { aq[1] = t1 + t2; q2 = t1 - t2; }
+                    if constexpr (h == 12) { t3 = f[4] - f[2]; d31 = f[3] - f[1]; }
+                    if constexpr (h == 13) { q3 = t3 + 2.f * d31; o4 = t3 - 2.f * d31; }
+                    if constexpr (h == 14) o5 = 4.f * f[1] + (f[5] - 5.f * f[3]);
+                    if constexpr (h == 16) { aq[2] = q2; aq[3] = q3; }                              // dead since mini-step 7
                 }
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[r][s], aq[r][s], acc[r], 0, 0, 0);
-                if constexpr (do_xf && r == 5) aq[5] = o5;
-                // issue order: one MFMA, then one slice of the step's other work in its shadow
-#define W4_MFMA __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#define W4_VMEM __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-#define W4_DSRD(n) if constexpr (do_xf && (r == 0 || r == 1)) __builtin_amdgcn_sched_group_barrier(0x100, n, 0);
-#define W4_VALU(n) if constexpr (do_xf && r >= 1) __builtin_amdgcn_sched_group_barrier(0x002, n, 0);
-#define W4_HALO_LD(n) if constexpr (ld && r == 0) __builtin_amdgcn_sched_group_barrier(0x020, n, 0);
-#define W4_HALO_ST(n)                                                                                     \
-                if constexpr (st && r == 5) {                                                             \
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
-                    __builtin_amdgcn_sched_group_barrier(0x200, n, 0);                                    \
+                // ---- halo store of the stage loaded one stage ago ----
+                if constexpr (st) {
+                    if constexpr (h == 16) st_addr();
+                    if constexpr (h >= 17 && h <= 22) *(f32x4*)(store_to + saddr + (h - 17) * 64 * W4_RSTR) = rawreg[h - 17];
                 }
-                W4_MFMA W4_VMEM W4_DSRD(2) W4_VALU(6) W4_HALO_ST(2)
-                W4_MFMA W4_DSRD(2) W4_VALU(6) W4_HALO_LD(2) W4_HALO_ST(2)
-                W4_MFMA W4_DSRD(1) W4_VALU(6) W4_HALO_LD(2) W4_HALO_ST(1)
-                W4_MFMA W4_DSRD(1) W4_VALU(6) W4_HALO_LD(2) W4_HALO_ST(1)
-#undef W4_MFMA
-#undef W4_VMEM
-#undef W4_DSRD
-#undef W4_VALU
-#undef W4_HALO_LD
-#undef W4_HALO_ST
+                if constexpr (do_xf && h == 23) { aq[4] = o4; aq[5] = o5; }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // the MFMA first, everything else behind it
                 __builtin_amdgcn_sched_barrier(0);
             };
-            step(std::integral_constant<int, 0>{});
-            step(std::integral_constant<int, 1>{});
-            step(std::integral_constant<int, 2>{});
-            step(std::integral_constant<int, 3>{});
-            step(std::integral_constant<int, 4>{});
-            step(std::integral_constant<int, 5>{});
+            [&]<int... I>(std::integer_sequence<int, I...>) { (half(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, 24>{});
             wso += 6144;
         };
         constexpr std::true_type T{};
@@ -238,8 +255,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
         raw_store(Rs);
         __syncthreads();
         raw_load(W4_KR * 4);                                // stages past the end read neighbouring data or zeros, never consumed
-        xf_read(Rs, 0); xf_cols(0);
-        xf_read(Rs, 3); xf_cols(3);
+        xf_addr();
+        xf_read3(Rs, 0); xf_cols(0);
+        xf_read3(Rs, 3); xf_cols(3);
         rows_012(aq); rows_34(aq); rows_5();
         aq[4] = o4; aq[5] = o5;
 
@@ -258,6 +276,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
     else if (wj == 2) main_loop(std::integral_constant<int, 2>{});
     else main_loop(std::integral_constant<int, 3>{});
     __syncthreads();
+    if constexpr (DIAG != 0) {
+        if (a.dbg && blockIdx.x < 32) {
+            unsigned* d32 = (unsigned*)a.dbg + blockIdx.x * 384;
+            for (int i = tid; i < 384; i += 256) d32[i] = steplog[i];
+        }
+        __syncthreads();
+    }
 
     // ---- epilogue -------------------------------------------------------------------------------------------------------------------
     // lane (li = tile, lh): acc[r][e16] = M[row r][column wj][channel 8 (e16 >> 2) + 4 lh + (e16 & 3)][tile li]
@@ -367,7 +392,11 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv3x3_wino4: bad grid %lld", blocks); return -1; }
     a.xcd_order = 1;
     const dim3 g((unsigned)blocks);
-    if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X>), g, dim3(256), 0, s, a);
+    static const int diag_env = getenv("ADAIN_W4_DIAG") ? atoi(getenv("ADAIN_W4_DIAG")) : 0;
+    if (a.dbg && diag_env == 2 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 2>), g, dim3(256), 0, s, a);
+    else if (a.dbg && diag_env == 3 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 3>), g, dim3(256), 0, s, a);
+    else if (a.dbg && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 1>), g, dim3(256), 0, s, a);
+    else if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X>), g, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a);
     return check_launch("conv3x3_wino4");
 }
