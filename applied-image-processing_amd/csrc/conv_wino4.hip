@@ -75,7 +75,8 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
 // DIAG (tools/wino4_probe.py, not the product path): 1 = a shader-clock stamp per 8-MFMA double step of the first 32 workgroups,
 // 2 = the same with LDS padded to one workgroup per CU
 template <int MODE, int DIAG = 0>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(ConvArgs a) {
+    constexpr bool RING12 = DIAG == 2;      // experiment (one workgroup per CU has the registers): a whole chunk of weights ahead
     __shared__ __attribute__((aligned(16))) float smem[DIAG >= 2 ? W4_PEX + 8192 : (DIAG == 1 ? W4_PEX + 1024 : W4_PEX)];
     float* const Rs = smem;
     unsigned* const steplog = (unsigned*)(smem + W4_PEX);     // DIAG: [wave][96] low words of s_memtime
@@ -95,11 +96,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
     // block -> (channel tile fastest, pixel tile, image) inside a contiguous per-XCD range (halo reuse in L2)
     const int tiles = a.tiles_x * a.tiles_y;
     const int nct = a.cout / 32;
-    int lid = blockIdx.x;
+    int lid = blockIdx.x, ct, pt, img;
     if (a.xcd_order && (gridDim.x & 7) == 0) lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
-    const int ct = lid % nct; lid /= nct;
-    const int pt = lid % tiles;
-    const int img = lid / tiles;
+    if (a.xcd_order == 2) {          // pixel tile fastest: the workgroups resident on an XCD share one or two channel tiles' weights
+        pt = lid % tiles; lid /= tiles;
+        ct = lid % nct;
+        img = lid / nct;
+    } else {                         // channel tile fastest: they share halos
+        ct = lid % nct; lid /= nct;
+        pt = lid % tiles;
+        img = lid / tiles;
+    }
     const int tx0 = (pt % a.tiles_x) * 32, ty0 = (pt / a.tiles_x) * 8;
     const int nst = a.cin / W4_KR;
     const int nch = a.cin / 8;
@@ -131,10 +138,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
     };
 
     // ---- weights: one b128 fragment per step (row position r), ring slot = r, loaded 5 steps ahead ---------------------------
-    f32x4 bq[6];
+    f32x4 bq[RING12 ? 12 : 6];
     int wso = ((ct * 4 + wj) * nch) * 6144;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bq[r] = buf_load4(wsr, wvo, wso + r * 1024);
+    for (int r = 0; r < (RING12 ? 6 : 4); ++r) bq[r] = buf_load4(wsr, wvo, wso + r * 1024);
 
     f32x16 acc[6];
 #pragma unroll
@@ -195,8 +202,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
         // 412 cycles per 4 instead of 256 + issue overheads), and left to itself the scheduler builds exactly those chains.
         // XF: transform the next chunk's patches meanwhile; ST: the last third also writes the staged halo registers to LDS;
         // LD: the halo loads two stages ahead.  Weight ring: slot = row position, refilled as soon as its MFMAs have issued.
-        auto chunk = [&](const float* nsrc, auto XFC, auto STC, auto LDC, int raw_soff, float* store_to) {
+        auto chunk = [&](const float* nsrc, auto XFC, auto STC, auto LDC, int raw_soff, float* store_to, auto PARC) {
             constexpr bool do_xf = decltype(XFC)::value, st = decltype(STC)::value, ld = decltype(LDC)::value;
+            constexpr int par = RING12 ? decltype(PARC)::value : 0;
             auto half = [&](auto HH) {
                 constexpr int h = decltype(HH)::value;          // 0..23: mini-step m = h / 2 (d = m / 4, s = m % 4), b = second MFMA
                 constexpr int m = h / 2, b = h & 1, d = m / 4, sidx = m & 3, r = 2 * d + b;
@@ -205,9 +213,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
                     if (lane_now() == 0 && nlog < 96) steplog[WJ * 96 + nlog] = tnow;
                     ++nlog;
                 }
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[r][sidx], aq[r][sidx], acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[6 * par + r][sidx], aq[r][sidx], acc[r], 0, 0, 0);
                 // ---- weight ring: (this chunk) slots 4, 5 at mini-steps 0, 1; (next chunk) slots 0, 1 at 4, 5; slots 2, 3 at 8, 9 ----
-                if constexpr (b == 0) {
+                if constexpr (RING12) {
+                    if constexpr (b == 0 && m < 6) bq[6 * (1 - par) + m] = buf_load4(wsr, wvo, wso + 6144 + m * 1024);
+                } else if constexpr (b == 0) {
                     if constexpr (m == 0) bq[4] = buf_load4(wsr, wvo, wso + 4 * 1024);
                     if constexpr (m == 1) bq[5] = buf_load4(wsr, wvo, wso + 5 * 1024);
                     if constexpr (m == 4) bq[0] = buf_load4(wsr, wvo, wso + 6144);
@@ -249,6 +259,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
         };
         constexpr std::true_type T{};
         constexpr std::false_type F{};
+        constexpr std::integral_constant<int, 0> P0{};
+        constexpr std::integral_constant<int, 1> P1{};
 
         // ---- prologue --------------------------------------------------------------------------------------------------------------
         raw_load(0);
@@ -264,12 +276,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(ConvArgs a) {
         for (int s = 0; s + 1 < nst; ++s) {
             const float* cur = Rs + (s & 1) * W4_RBUF;
             float* nxt = Rs + ((s + 1) & 1) * W4_RBUF;
-            chunk(cur + 8, T, T, F, 0, nxt);                // channels 0..7; prepares 8..15; writes the next stage's halo
+            chunk(cur + 8, T, T, F, 0, nxt, P0);            // channels 0..7; prepares 8..15; writes the next stage's halo
             __syncthreads();
-            chunk(nxt, T, F, T, (s + 2) * W4_KR * 4, nullptr);      // channels 8..15; prepares the next stage; loads two stages ahead
+            chunk(nxt, T, F, T, (s + 2) * W4_KR * 4, nullptr, P1);  // channels 8..15; prepares the next stage; loads two stages ahead
         }
-        chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr);
-        chunk(Rs, F, F, F, 0, nullptr);
+        chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, P0);
+        chunk(Rs, F, F, F, 0, nullptr, P1);
     };
     if (wj == 0) main_loop(std::integral_constant<int, 0>{});
     else if (wj == 1) main_loop(std::integral_constant<int, 1>{});
@@ -390,7 +402,8 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     a.tiles_y = (a.H + 7) / 8;
     const long long blocks = (long long)a.tiles_x * a.tiles_y * (a.cout / 32) * a.n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv3x3_wino4: bad grid %lld", blocks); return -1; }
-    a.xcd_order = 1;
+    static const int order_env = getenv("ADAIN_W4_ORDER") ? atoi(getenv("ADAIN_W4_ORDER")) : 1;
+    a.xcd_order = order_env;
     const dim3 g((unsigned)blocks);
     static const int diag_env = getenv("ADAIN_W4_DIAG") ? atoi(getenv("ADAIN_W4_DIAG")) : 0;
     if (a.dbg && diag_env == 2 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 2>), g, dim3(256), 0, s, a);

@@ -53,6 +53,7 @@ def probe(cin, cout, h):
         sel = dt[:, :, k::6]
         print(f"   step {k:2d} {NAMES[k]:36s}: median {sel.median():.0f}  mean {sel.mean():.0f}  p90 {sel.quantile(0.9):.0f}")
     print("   workgroup 0 wave 0, first 24 steps:", [int(v) for v in dt[0, 0, :24].tolist()])
+    print("   last stage (2 chunks without staging; the last without transform), medians:", [int(dt[:, :, nsteps - 7 + k].median()) for k in range(6)])
 
 
 for shape in ((256, 256, 256), (64, 64, 1024)):
