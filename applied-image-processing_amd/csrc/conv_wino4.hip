@@ -75,8 +75,7 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
 // DIAG (tools/wino4_probe.py, not the product path): 1 = a shader-clock stamp per 8-MFMA double step of the first 32 workgroups,
 // 2 = the same with LDS padded to one workgroup per CU
 template <int MODE, int DIAG = 0>
-__global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(ConvArgs a) {
-    constexpr bool RING12 = DIAG == 2;      // experiment (one workgroup per CU has the registers): a whole chunk of weights ahead
+__global__ __launch_bounds__(256, DIAG >= 2 ? 1 : 2) void conv3x3_wino4_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[DIAG >= 2 ? W4_PEX + 8192 : (DIAG == 1 ? W4_PEX + 1024 : W4_PEX)];
     float* const Rs = smem;
     unsigned* const steplog = (unsigned*)(smem + W4_PEX);     // DIAG: [wave][96] low words of s_memtime
@@ -138,10 +137,10 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     };
 
     // ---- weights: one b128 fragment per step (row position r), ring slot = r, loaded 5 steps ahead ---------------------------
-    f32x4 bq[RING12 ? 12 : 6];
+    f32x4 bq[6];
     int wso = ((ct * 4 + wj) * nch) * 6144;
 #pragma unroll
-    for (int r = 0; r < (RING12 ? 6 : 4); ++r) bq[r] = buf_load4(wsr, wvo, wso + r * 1024);
+    for (int r = 0; r < 4; ++r) bq[r] = buf_load4(wsr, wvo, wso + r * 1024);
 
     f32x16 acc[6];
 #pragma unroll
@@ -202,9 +201,8 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         // 412 cycles per 4 instead of 256 + issue overheads), and left to itself the scheduler builds exactly those chains.
         // XF: transform the next chunk's patches meanwhile; ST: the last third also writes the staged halo registers to LDS;
         // LD: the halo loads two stages ahead.  Weight ring: slot = row position, refilled as soon as its MFMAs have issued.
-        auto chunk = [&](const float* nsrc, auto XFC, auto STC, auto LDC, int raw_soff, float* store_to, auto PARC) {
+        auto chunk = [&](const float* nsrc, auto XFC, auto STC, auto LDC, int raw_soff, float* store_to) {
             constexpr bool do_xf = decltype(XFC)::value, st = decltype(STC)::value, ld = decltype(LDC)::value;
-            constexpr int par = RING12 ? decltype(PARC)::value : 0;
             auto half = [&](auto HH) {
                 constexpr int h = decltype(HH)::value;          // 0..23: mini-step m = h / 2 (d = m / 4, s = m % 4), b = second MFMA
                 constexpr int m = h / 2, b = h & 1, d = m / 4, sidx = m & 3, r = 2 * d + b;
@@ -213,11 +211,9 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                     if (lane_now() == 0 && nlog < 96) steplog[WJ * 96 + nlog] = tnow;
                     ++nlog;
                 }
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[6 * par + r][sidx], aq[r][sidx], acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[r][sidx], aq[r][sidx], acc[r], 0, 0, 0);
                 // ---- weight ring: (this chunk) slots 4, 5 at mini-steps 0, 1; (next chunk) slots 0, 1 at 4, 5; slots 2, 3 at 8, 9 ----
-                if constexpr (RING12) {
-                    if constexpr (b == 0 && m < 6) bq[6 * (1 - par) + m] = buf_load4(wsr, wvo, wso + 6144 + m * 1024);
-                } else if constexpr (b == 0) {
+                if constexpr (b == 0) {
                     if constexpr (m == 0) bq[4] = buf_load4(wsr, wvo, wso + 4 * 1024);
                     if constexpr (m == 1) bq[5] = buf_load4(wsr, wvo, wso + 5 * 1024);
                     if constexpr (m == 4) bq[0] = buf_load4(wsr, wvo, wso + 6144);
@@ -259,8 +255,6 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         };
         constexpr std::true_type T{};
         constexpr std::false_type F{};
-        constexpr std::integral_constant<int, 0> P0{};
-        constexpr std::integral_constant<int, 1> P1{};
 
         // ---- prologue --------------------------------------------------------------------------------------------------------------
         raw_load(0);
@@ -276,12 +270,12 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         for (int s = 0; s + 1 < nst; ++s) {
             const float* cur = Rs + (s & 1) * W4_RBUF;
             float* nxt = Rs + ((s + 1) & 1) * W4_RBUF;
-            chunk(cur + 8, T, T, F, 0, nxt, P0);            // channels 0..7; prepares 8..15; writes the next stage's halo
+            chunk(cur + 8, T, T, F, 0, nxt);                // channels 0..7; prepares 8..15; writes the next stage's halo
             __syncthreads();
-            chunk(nxt, T, F, T, (s + 2) * W4_KR * 4, nullptr, P1);  // channels 8..15; prepares the next stage; loads two stages ahead
+            chunk(nxt, T, F, T, (s + 2) * W4_KR * 4, nullptr);      // channels 8..15; prepares the next stage; loads two stages ahead
         }
-        chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, P0);
-        chunk(Rs, F, F, F, 0, nullptr, P1);
+        chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr);
+        chunk(Rs, F, F, F, 0, nullptr);
     };
     if (wj == 0) main_loop(std::integral_constant<int, 0>{});
     else if (wj == 1) main_loop(std::integral_constant<int, 1>{});
