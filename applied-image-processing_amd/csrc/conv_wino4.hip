@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, DIAG >= 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         const int idx = tid + k * 256;
         const int hp = min(idx >> 2, W4_HALO - 1), q = idx & 3;
         const int hy = hp / W4_HALO_W, hx = hp - hy * W4_HALO_W;
-        int y = reflect1((DIAG == 3 ? 0 : ty0) + hy - 1, a.H), x = reflect1((DIAG == 3 ? 0 : tx0) + hx - 1, a.W);   // DIAG 3: timing-only, every halo from L2
+        int y = reflect1(ty0 + hy - 1, a.H), x = reflect1(tx0 + hx - 1, a.W);
         if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
         roff[k] = ((y * a.Ws + x) * a.cin + q * 4) * 4;
     }
@@ -401,7 +401,6 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     const dim3 g((unsigned)blocks);
     static const int diag_env = getenv("ADAIN_W4_DIAG") ? atoi(getenv("ADAIN_W4_DIAG")) : 0;
     if (a.dbg && diag_env == 2 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 2>), g, dim3(256), 0, s, a);
-    else if (a.dbg && diag_env == 3 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 3>), g, dim3(256), 0, s, a);
     else if (a.dbg && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 1>), g, dim3(256), 0, s, a);
     else if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X>), g, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a);

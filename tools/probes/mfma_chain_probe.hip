@@ -51,6 +51,69 @@ __global__ __launch_bounds__(256, 1) void chain_ops(float* out, unsigned long lo
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// 8 MFMAs per step on 2 accumulators + NL weight-like loads (b128 per lane, 1 KB per wave, streamed from a `bytes`-sized
+// buffer, consumed 3 steps later as the A operand), every CU active: what do the loads cost the matrix pipe?
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+template <int NL>
+__global__ __launch_bounds__(256, 2) void chain_loads(float* out, unsigned long long* cyc, int iters, const float* w, unsigned bytes) {
+    f32x16 acc[2];
+    for (int k = 0; k < 2; ++k)
+        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, bytes, 0x00020000);
+    const int lane_off = (threadIdx.x & 63) * 16;
+    unsigned soff = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * 65536u % bytes);
+    f32x4 ring[4][2];
+    for (int p = 0; p < 4; ++p)
+        for (int n = 0; n < 2; ++n) ring[p][n] = f32x4{1.f, 2.f, 3.f, 4.f};
+    float b = threadIdx.x * 0.001f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[st][0][s], b, acc[0], 0, 0, 0);
+                if (s < NL) {
+                    auto v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, soff, 0);
+                    ring[(st + 3) & 3][s & 1] = __builtin_bit_cast(f32x4, v);
+                    soff = soff + 1024u < bytes ? soff + 1024u : 0u;
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[st][1][s], b, acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float sum = 0.f;
+    for (int k = 0; k < 2; ++k)
+        for (int e = 0; e < 16; ++e) sum += acc[k][e];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int NL>
+static void run_loads(int blocks_per_cu, unsigned bytes) {
+    float *out, *w;
+    unsigned long long* cyc;
+    const int blocks = 256 * blocks_per_cu;
+    hipMalloc(&out, blocks * 256 * sizeof(float));
+    hipMalloc(&w, bytes);
+    hipMemset(w, 0, bytes);
+    hipMalloc(&cyc, blocks * sizeof(unsigned long long));
+    const int iters = 500;
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((chain_loads<NL>), dim3(blocks), dim3(256), 0, 0, out, cyc, iters, w, bytes);
+    hipDeviceSynchronize();
+    unsigned long long h[4096];
+    hipMemcpy(h, cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double sum = 0;
+    for (int i = 0; i < blocks; ++i) sum += (double)h[i];
+    printf("%d b128 loads per 8 MFMAs from a %.1f MB buffer, %d wave(s) per SIMD: %.1f cycles per 8 MFMAs per wave (ideal %d)\n", NL, bytes / 1048576.0,
+           blocks_per_cu, sum / blocks / ((double)iters * 4), 512 * blocks_per_cu);
+    hipFree(out); hipFree(w); hipFree(cyc);
+}
+
 template <int K>
 static void run_ops() {
     float *out, *in;
@@ -97,5 +160,9 @@ int main() {
         run<1>(w); run<2>(w); run<3>(w); run<4>(w); run<6>(w);
     }
     run_ops<1>(); run_ops<2>(); run_ops<6>();
+    for (int bpc = 1; bpc <= 2; ++bpc) {
+        run_loads<0>(bpc, 1u << 20); run_loads<1>(bpc, 1u << 20); run_loads<2>(bpc, 1u << 20); run_loads<4>(bpc, 1u << 20);
+        run_loads<2>(bpc, 6u << 20); run_loads<4>(bpc, 6u << 20); run_loads<2>(bpc, 64u << 20);
+    }
     return 0;
 }
