@@ -146,6 +146,27 @@ def test_conv3x3_winograd_persistent_many_tiles(rt, mode, shape):
           F.max_pool2d(F.relu(pre), 2, 2, 0, ceil_mode=True))
 
 
+@pytest.mark.parametrize("mode,shape", [("direct", (1, 64, 128, 250, 203)), ("direct", (2, 32, 64, 131, 257)), ("up", (1, 64, 64, 121, 150)),
+                                        ("direct", (3, 128, 32, 6, 40)), ("direct", (1, 256, 256, 64, 96))])
+def test_conv3x3_winograd_f43_full_grids(rt, mode, shape):
+    """The F(4,3) x F(2,3) form on grids that fill every CU with two workgroups (co-resident waves queueing LDS and VMEM
+    work), ragged edges (H, W not multiples of the 8 x 32 tile), several images and channel tiles; direct, ReLU, pooled."""
+    n, cin, cout, hs, ws = shape
+    x = T(synth.uniform_sym(420 + cin, (n, cin, hs, ws), 1.0))
+    w = T(synth.uniform_sym(520 + cout, (cout, cin, 3, 3), (6.0 / (9 * cin)) ** 0.5))
+    b = T(synth.uniform_sym(620 + cout, (cout,), 0.1))
+    src = F.interpolate(x, scale_factor=2, mode="nearest") if mode == "up" else x
+    pre = F.conv2d(F.pad(src, (1, 1, 1, 1), mode="reflect"), w, b)
+    xg = x.cuda().permute(0, 2, 3, 1).contiguous()
+    packed = rt.conv3x3_wino_pack(w.cuda(), 5)
+    m = rt.SRC_UP2X if mode == "up" else rt.SRC_DIRECT
+    out = rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=False, m_tiles=5)
+    close(out.permute(0, 3, 1, 2), pre)
+    assert torch.equal(out, rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=False, m_tiles=5))      # deterministic
+    close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True, pool_out=True, m_tiles=5).permute(0, 3, 1, 2),
+          F.max_pool2d(F.relu(pre), 2, 2, 0, ceil_mode=True))
+
+
 def test_conv3x3_rejects_bad_shapes(rt):
     x = torch.zeros(1, 4, 4, 24, device="cuda")
     with pytest.raises(rt.AdainHipError):
