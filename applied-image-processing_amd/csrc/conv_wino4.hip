@@ -19,6 +19,10 @@
 //   * the raw halo is staged 16 channels at a time (global -> registers -> LDS), one barrier per 48 MFMAs per wave;
 //   * epilogue: P_j = A4^T M_j per wave (4 values), the four columns meet in LDS (64 KiB, XOR-swizzled b128), then
 //     Y = P A2: bias, ReLU, optional 2x2 max-pool (a tile holds two pool windows), b128 buffer stores.
+//
+// Tried and measured without effect (tools/tune_conv.py, all 13 layer shapes, +-1 %): pixel-tile-fastest and grouped
+// block -> tile orders (weights L2-resident), raised wave priority outside the main loop, halo loads spread differently,
+// a 12-slot weight ring (512-register build).  See DESIGN.md 4(C) for what the probes say bounds the kernel.
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
