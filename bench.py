@@ -288,6 +288,7 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the AdaIN path has no CPU fallback)")
+    local_rank %= torch.cuda.device_count()           # one rank per GPU on a node; wraps only in single-GPU rehearsals
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ      # torch.distributed.run sets RANK even for one process
