@@ -76,14 +76,23 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
-// DIAG (tools/wino4_probe.py, not the product path): 1 = a shader-clock stamp per 8-MFMA double step of the first 32 workgroups,
-// 2 = the same with LDS padded to one workgroup per CU
-template <int MODE, int DIAG = 0>
-__global__ __launch_bounds__(256, DIAG >= 2 ? 1 : 2) void conv3x3_wino4_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[DIAG >= 2 ? W4_PEX + 8192 : (DIAG == 1 ? W4_PEX + 1024 : W4_PEX)];
+// DIAG (tools/wino4_probe.py, tools/wino4_phase_probe.py; not the product path): 1 = a shader-clock stamp per 8-MFMA double step of
+// the first 32 workgroups, 2 = the same with LDS padded to one workgroup per CU, 3 = four s_memrealtime phase stamps per wave
+// (entry, main-loop start / end, exit).
+// PERSIST: a workgroup walks a list of tiles (grid = 2 per CU; XCD x owns a contiguous range of the tile list, channel tile
+// fastest) instead of one: the next tile's first halo stage is loaded during the current tile's last stages and its first
+// weight fragments replace the ring's run-off loads, so a tile starts with an LDS write + barrier + transform instead of a cold
+// HBM round trip (tools/wino4_phase_probe.py: 3.4-4.1 us of prologue per one-tile workgroup; with cin = 64 both workgroups of a
+// CU are inside their main loops only 22 % of the time).  The wave priority alternates per tile between the two halves of the
+// grid (the SIMD arbiter prefers the older wave; see conv_wino3.hip).
+template <int MODE, int DIAG = 0, bool PERSIST = false>
+__global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(ConvArgs a, int items, int prio_mode) {
+    __shared__ __attribute__((aligned(16))) float smem[DIAG == 2 ? W4_PEX + 8192 : (DIAG == 1 ? W4_PEX + 1024 : W4_PEX)];
     float* const Rs = smem;
-    unsigned* const steplog = (unsigned*)(smem + W4_PEX);     // DIAG: [wave][96] low words of s_memtime
+    unsigned* const steplog = (unsigned*)(smem + W4_PEX);     // DIAG 1, 2: [wave][96] low words of s_memtime
     int nlog = 0;
+    unsigned long long phase[4] = {0, 0, 0, 0};
+    if constexpr (DIAG == 3) phase[0] = __builtin_amdgcn_s_memrealtime();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -100,8 +109,17 @@ __global__ __launch_bounds__(256, DIAG >= 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     const int tiles = a.tiles_x * a.tiles_y;
     const int nct = a.cout / 32;
     int lid = blockIdx.x, ct, pt, img;
-    if (a.xcd_order && (gridDim.x & 7) == 0) lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
-    if (a.xcd_order == 2) {          // pixel tile fastest: the workgroups resident on an XCD share one or two channel tiles' weights
+    // persistent form: the tile list of this workgroup = items lo + slot, lo + slot + stride, ... below hi
+    const int stride = gridDim.x >> 3;
+    const int lo = (int)((long long)items * (blockIdx.x & 7) / 8), hi = (int)((long long)items * ((blockIdx.x & 7) + 1) / 8);
+    int item = lo + (blockIdx.x >> 3);
+    if constexpr (PERSIST) {
+        if (item >= hi) return;
+        lid = item;
+    } else if (a.xcd_order && (gridDim.x & 7) == 0) {
+        lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
+    }
+    if (!PERSIST && a.xcd_order == 2) {          // pixel tile fastest: the workgroups resident on an XCD share one or two channel tiles' weights
         pt = lid % tiles; lid /= tiles;
         ct = lid % nct;
         img = lid / nct;
@@ -110,24 +128,30 @@ __global__ __launch_bounds__(256, DIAG >= 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         pt = lid % tiles;
         img = lid / tiles;
     }
-    const int tx0 = (pt % a.tiles_x) * 32, ty0 = (pt / a.tiles_x) * 8;
+    int tx0 = (pt % a.tiles_x) * 32, ty0 = (pt / a.tiles_x) * 8;
     const int nst = a.cin / W4_KR;
     const int nch = a.cin / 8;
 
-    const rsrc_t src = make_rsrc(a.in + (size_t)img * a.Hs * a.Ws * a.cin, (unsigned)a.Hs * a.Ws * a.cin * 4u);
+    const unsigned src_bytes = (unsigned)a.Hs * a.Ws * a.cin * 4u;
+    const size_t src_img = (size_t)a.Hs * a.Ws * a.cin;
+    rsrc_t src = make_rsrc(a.in + img * src_img, src_bytes);
     const rsrc_t wsr = make_rsrc(a.wpk, (unsigned)a.cin * a.cout * 96u);
 
     // ---- raw halo staging: 340 pixels x 4 quads over 256 threads x 6 items ---------------------------------------------------
     int roff[W4_RITEMS];
+    auto halo_offsets = [&](int x0, int y0) {
+        const int t = PERSIST ? (lane_now() | (wj << 6)) : tid;        // persistent: recomputed per tile, nothing hoisted
 #pragma unroll
-    for (int k = 0; k < W4_RITEMS; ++k) {
-        const int idx = tid + k * 256;
-        const int hp = min(idx >> 2, W4_HALO - 1), q = idx & 3;
-        const int hy = hp / W4_HALO_W, hx = hp - hy * W4_HALO_W;
-        int y = reflect1(ty0 + hy - 1, a.H), x = reflect1(tx0 + hx - 1, a.W);
-        if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
-        roff[k] = ((y * a.Ws + x) * a.cin + q * 4) * 4;
-    }
+        for (int k = 0; k < W4_RITEMS; ++k) {
+            const int idx = t + k * 256;
+            const int hp = min(idx >> 2, W4_HALO - 1), q = idx & 3;
+            const int hy = hp / W4_HALO_W, hx = hp - hy * W4_HALO_W;
+            int y = reflect1(y0 + hy - 1, a.H), x = reflect1(x0 + hx - 1, a.W);
+            if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
+            roff[k] = ((y * a.Ws + x) * a.cin + q * 4) * 4;
+        }
+    };
+    halo_offsets(tx0, ty0);
     f32x4 rawreg[W4_RITEMS];
     auto raw_load = [&](int soff) {
 #pragma unroll
@@ -151,6 +175,88 @@ __global__ __launch_bounds__(256, DIAG >= 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+    // ---- epilogue (a lambda: the persistent form runs it inside the tile loop) ------------------------------------------------------
+    // lane (li = tile, lh): acc[r][e16] = M[row r][column wj][channel 8 (e16 >> 2) + 4 lh + (e16 & 3)][tile li]
+    auto epilogue = [&]() {
+    {
+        const int le = lane_now(), li = le & 31, lh = le >> 5;
+        float* Pw = smem + (wj * 4) * (32 * 32) + li * 32;
+        const int sw = (li >> 1) & 7;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            f32x4 P0, P1, P2, P3;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = rq * 4 + e;
+                const float s1 = acc[1][k] + acc[2][k], d1 = acc[1][k] - acc[2][k];
+                const float s2 = acc[3][k] + acc[4][k], d2 = acc[3][k] - acc[4][k];
+                P0[e] = acc[0][k] + s1 + s2;               // A4^T = (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,0) (0,1,-1,8,-8,1)
+                P1[e] = d1 + 2.f * d2;
+                P2[e] = s1 + 4.f * s2;
+                P3[e] = d1 + 8.f * d2 + acc[5][k];
+            }
+            const int slot = ((2 * rq + lh) ^ sw) << 2;    // channel quad of the 32, XOR-swizzled: conflict-free both ways
+            *(f32x4*)(Pw + slot) = P0;
+            *(f32x4*)(Pw + 1 * 32 * 32 + slot) = P1;
+            *(f32x4*)(Pw + 2 * 32 * 32 + slot) = P2;
+            *(f32x4*)(Pw + 3 * 32 * 32 + slot) = P3;
+        }
+    }
+    __syncthreads();
+    {
+        const int le = lane_now(), q8 = le & 7, tt = le >> 3;
+        const int tl = wj * 8 + tt;
+        const float* Pr = smem + tl * 32 + ((q8 ^ ((tl >> 1) & 7)) << 2);
+        const f32x4 bias4 = *(const f32x4*)(a.bias + ct * 32 + 4 * q8);
+        const int Ho = a.pool_out ? (a.H + 1) >> 1 : a.H, Wo = a.pool_out ? (a.W + 1) >> 1 : a.W;
+        const rsrc_t dst = make_rsrc(a.out + (size_t)img * Ho * Wo * a.cout, (unsigned)(Ho * Wo * a.cout) * 4u);
+        const int oy = ty0 + 4 * (tl >> 4), ox = tx0 + 2 * (tl & 15);
+        const int cbyte = (ct * 32 + 4 * q8) * 4;
+        const bool colok0 = ox < a.W, colok1 = ox + 1 < a.W;
+        f32x4 y[4][2], P[4][4];
+#pragma unroll
+        for (int ap = 0; ap < 4; ++ap)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) P[ap][j] = *(const f32x4*)(Pr + (j * 4 + ap) * (32 * 32));
+        if constexpr (PERSIST) {
+            __syncthreads();                               // every wave has its P values: the LDS image is free again
+            raw_store(Rs);                                 // the next tile's first halo stage (loaded during this tile)
+        }
+#pragma unroll
+        for (int ap = 0; ap < 4; ++ap) {
+            y[ap][0] = P[ap][0] + P[ap][1] + P[ap][2] + bias4;          // A2 = columns (1,1,1,0), (0,1,-1,-1)
+            y[ap][1] = P[ap][1] - P[ap][2] - P[ap][3] + bias4;
+            if (a.relu) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                y[ap][0] = max4(y[ap][0], z);
+                y[ap][1] = max4(y[ap][1], z);
+            }
+        }
+        if (a.pool_out) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {               // two pool windows per tile: rows (0,1) and (2,3)
+                const int r0 = oy + 2 * h2;
+                f32x4 v = y[2 * h2][0];
+                if (colok1) v = max4(v, y[2 * h2][1]);
+                if (r0 + 1 < a.H) {
+                    v = max4(v, y[2 * h2 + 1][0]);
+                    if (colok1) v = max4(v, y[2 * h2 + 1][1]);
+                }
+                const int off = (((r0 >> 1) * Wo + (ox >> 1)) * a.cout) * 4 + cbyte;
+                buf_store4(dst, v, (r0 < a.H && colok0) ? off : 0x7fffffff);
+            }
+        } else {
+#pragma unroll
+            for (int ap = 0; ap < 4; ++ap) {
+                const int off = (((oy + ap) * a.W + ox) * a.cout) * 4 + cbyte;
+                const bool rowok = oy + ap < a.H;
+                buf_store4(dst, y[ap][0], (rowok && colok0) ? off : 0x7fffffff);
+                buf_store4(dst, y[ap][1], (rowok && colok1) ? off + a.cout * 4 : 0x7fffffff);
+            }
+        }
+    }
+    };
 
     // the main loop is instantiated once per transform column (WJ compile-time): see conv_wino.hip
     auto main_loop = [&](auto WJC) {
@@ -205,12 +311,12 @@ __global__ __launch_bounds__(256, DIAG >= 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         // 412 cycles per 4 instead of 256 + issue overheads), and left to itself the scheduler builds exactly those chains.
         // XF: transform the next chunk's patches meanwhile; ST: the last third also writes the staged halo registers to LDS;
         // LD: the halo loads two stages ahead.  Weight ring: slot = row position, refilled as soon as its MFMAs have issued.
-        auto chunk = [&](const float* nsrc, auto XFC, auto STC, auto LDC, int raw_soff, float* store_to) {
+        auto chunk = [&](const float* nsrc, auto XFC, auto STC, auto LDC, int raw_soff, float* store_to, int wnext) {
             constexpr bool do_xf = decltype(XFC)::value, st = decltype(STC)::value, ld = decltype(LDC)::value;
             auto half = [&](auto HH) {
                 constexpr int h = decltype(HH)::value;          // 0..23: mini-step m = h / 2 (d = m / 4, s = m % 4), b = second MFMA
                 constexpr int m = h / 2, b = h & 1, d = m / 4, sidx = m & 3, r = 2 * d + b;
-                if constexpr (DIAG != 0 && (h % 8) == 0) {
+                if constexpr ((DIAG == 1 || DIAG == 2) && (h % 8) == 0) {
                     const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
                     if (lane_now() == 0 && nlog < 96) steplog[WJ * 96 + nlog] = tnow;
                     ++nlog;
@@ -220,10 +326,10 @@ __global__ __launch_bounds__(256, DIAG >= 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 if constexpr (b == 0) {
                     if constexpr (m == 0) bq[4] = buf_load4(wsr, wvo, wso + 4 * 1024);
                     if constexpr (m == 1) bq[5] = buf_load4(wsr, wvo, wso + 5 * 1024);
-                    if constexpr (m == 4) bq[0] = buf_load4(wsr, wvo, wso + 6144);
-                    if constexpr (m == 5) bq[1] = buf_load4(wsr, wvo, wso + 6144 + 1024);
-                    if constexpr (m == 8) bq[2] = buf_load4(wsr, wvo, wso + 6144 + 2 * 1024);
-                    if constexpr (m == 9) bq[3] = buf_load4(wsr, wvo, wso + 6144 + 3 * 1024);
+                    if constexpr (m == 4) bq[0] = buf_load4(wsr, wvo, wnext);
+                    if constexpr (m == 5) bq[1] = buf_load4(wsr, wvo, wnext + 1024);
+                    if constexpr (m == 8) bq[2] = buf_load4(wsr, wvo, wnext + 2 * 1024);
+                    if constexpr (m == 9) bq[3] = buf_load4(wsr, wvo, wnext + 3 * 1024);
                 }
                 // ---- halo loads two stages ahead, in the first two thirds of the chunk (regions 5, 7, 9, 11, 13, 15) ----
                 if constexpr (ld && b == 1 && h >= 5 && h <= 15) {
@@ -270,102 +376,91 @@ __global__ __launch_bounds__(256, DIAG >= 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         xf_read3(Rs, 3); xf_cols(3);
         rows_012(aq); rows_34(aq); rows_5();
         aq[4] = o4; aq[5] = o5;
+        if constexpr (DIAG == 3) phase[1] = __builtin_amdgcn_s_memrealtime();
 
-        for (int s = 0; s + 1 < nst; ++s) {
-            const float* cur = Rs + (s & 1) * W4_RBUF;
-            float* nxt = Rs + ((s + 1) & 1) * W4_RBUF;
-            chunk(cur + 8, T, T, F, 0, nxt);                // channels 0..7; prepares 8..15; writes the next stage's halo
-            __syncthreads();
-            chunk(nxt, T, F, T, (s + 2) * W4_KR * 4, nullptr);      // channels 8..15; prepares the next stage; loads two stages ahead
+        if constexpr (!PERSIST) {
+            for (int s = 0; s + 1 < nst; ++s) {
+                const float* cur = Rs + (s & 1) * W4_RBUF;
+                float* nxt = Rs + ((s + 1) & 1) * W4_RBUF;
+                chunk(cur + 8, T, T, F, 0, nxt, wso + 6144);                // channels 0..7; prepares 8..15; writes the next stage's halo
+                __syncthreads();
+                chunk(nxt, T, F, T, (s + 2) * W4_KR * 4, nullptr, wso + 6144);      // channels 8..15; prepares the next stage; loads two stages ahead
+            }
+            chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, wso + 6144);
+            chunk(Rs, F, F, F, 0, nullptr, wso + 6144);
+            if constexpr (DIAG == 3) phase[2] = __builtin_amdgcn_s_memrealtime();
+        } else {
+            int ntile = 0;
+            for (;;) {
+                // the tile after this one (or this one again when the list is exhausted: its loads are then never consumed)
+                const int nitem = item + stride < hi ? item + stride : item;
+                const int nct_ = nitem % nct, nr = nitem / nct, npt = nr % tiles, nimg = nr / tiles;
+                const int ntx0 = (npt % a.tiles_x) * 32, nty0 = (npt / a.tiles_x) * 8;
+                const int wso_next = ((nct_ * 4 + wj) * nch) * 6144;
+                if (prio_mode) {
+                    if ((ntile + (int)((blockIdx.x >> 3) >= (stride >> 1))) & 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+                ++ntile;
+                // the halo loads run two stages ahead: once the current tile's last stage has been requested (in iteration
+                // nst-3, or by the tile's entry code when nst == 2) the offsets switch to the next tile (loop tail, so that no
+                // branch splits the two chunks of a stage)
+                auto next_halo = [&]() {
+                    halo_offsets(ntx0, nty0);
+                    src = make_rsrc(a.in + nimg * src_img, src_bytes);
+                };
+                if (nst == 2) next_halo();
+                for (int s = 0; s + 1 < nst; ++s) {
+                    const float* cur = Rs + (s & 1) * W4_RBUF;
+                    float* nxt = Rs + ((s + 1) & 1) * W4_RBUF;
+                    chunk(cur + 8, T, T, F, 0, nxt, wso + 6144);
+                    __syncthreads();
+                    chunk(nxt, T, F, T, s == nst - 2 ? 0 : (s + 2) * W4_KR * 4, nullptr, wso + 6144);
+                    if (s == nst - 3) next_halo();
+                }
+                chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, wso + 6144);
+                chunk(Rs, F, F, F, 0, nullptr, wso_next);      // the ring's look-ahead continues in the next tile's weights
+                wso = wso_next;
+                __syncthreads();
+                epilogue();                                     // of (ct, img, tx0, ty0); also writes the next tile's first halo stage
+                if (item + stride >= hi) break;
+                item += stride;
+                ct = nct_; img = nimg; tx0 = ntx0; ty0 = nty0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+                __syncthreads();
+                raw_load(W4_KR * 4);
+                xf_addr();
+                xf_read3(Rs, 0); xf_cols(0);
+                xf_read3(Rs, 3); xf_cols(3);
+                rows_012(aq); rows_34(aq); rows_5();
+                aq[4] = o4; aq[5] = o5;
+            }
         }
-        chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr);
-        chunk(Rs, F, F, F, 0, nullptr);
     };
     if (wj == 0) main_loop(std::integral_constant<int, 0>{});
     else if (wj == 1) main_loop(std::integral_constant<int, 1>{});
     else if (wj == 2) main_loop(std::integral_constant<int, 2>{});
     else main_loop(std::integral_constant<int, 3>{});
+    if constexpr (PERSIST) return;
     __syncthreads();
-    if constexpr (DIAG != 0) {
+    if constexpr (DIAG == 1 || DIAG == 2) {
         if (a.dbg && blockIdx.x < 32) {
             unsigned* d32 = (unsigned*)a.dbg + blockIdx.x * 384;
             for (int i = tid; i < 384; i += 256) d32[i] = steplog[i];
         }
         __syncthreads();
     }
-
-    // ---- epilogue -------------------------------------------------------------------------------------------------------------------
-    // lane (li = tile, lh): acc[r][e16] = M[row r][column wj][channel 8 (e16 >> 2) + 4 lh + (e16 & 3)][tile li]
-    {
-        const int le = lane_now(), li = le & 31, lh = le >> 5;
-        float* Pw = smem + (wj * 4) * (32 * 32) + li * 32;
-        const int sw = (li >> 1) & 7;
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            f32x4 P0, P1, P2, P3;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = rq * 4 + e;
-                const float s1 = acc[1][k] + acc[2][k], d1 = acc[1][k] - acc[2][k];
-                const float s2 = acc[3][k] + acc[4][k], d2 = acc[3][k] - acc[4][k];
-                P0[e] = acc[0][k] + s1 + s2;               // A4^T = (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,0) (0,1,-1,8,-8,1)
-                P1[e] = d1 + 2.f * d2;
-                P2[e] = s1 + 4.f * s2;
-                P3[e] = d1 + 8.f * d2 + acc[5][k];
-            }
-            const int slot = ((2 * rq + lh) ^ sw) << 2;    // channel quad of the 32, XOR-swizzled: conflict-free both ways
-            *(f32x4*)(Pw + slot) = P0;
-            *(f32x4*)(Pw + 1 * 32 * 32 + slot) = P1;
-            *(f32x4*)(Pw + 2 * 32 * 32 + slot) = P2;
-            *(f32x4*)(Pw + 3 * 32 * 32 + slot) = P3;
-        }
-    }
-    __syncthreads();
-    {
-        const int le = lane_now(), q8 = le & 7, tt = le >> 3;
-        const int tl = wj * 8 + tt;
-        const float* Pr = smem + tl * 32 + ((q8 ^ ((tl >> 1) & 7)) << 2);
-        const f32x4 bias4 = *(const f32x4*)(a.bias + ct * 32 + 4 * q8);
-        const int Ho = a.pool_out ? (a.H + 1) >> 1 : a.H, Wo = a.pool_out ? (a.W + 1) >> 1 : a.W;
-        const rsrc_t dst = make_rsrc(a.out + (size_t)img * Ho * Wo * a.cout, (unsigned)(Ho * Wo * a.cout) * 4u);
-        const int oy = ty0 + 4 * (tl >> 4), ox = tx0 + 2 * (tl & 15);
-        const int cbyte = (ct * 32 + 4 * q8) * 4;
-        const bool colok0 = ox < a.W, colok1 = ox + 1 < a.W;
-        f32x4 y[4][2];
-#pragma unroll
-        for (int ap = 0; ap < 4; ++ap) {
-            f32x4 P[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) P[j] = *(const f32x4*)(Pr + (j * 4 + ap) * (32 * 32));
-            y[ap][0] = P[0] + P[1] + P[2] + bias4;          // A2 = columns (1,1,1,0), (0,1,-1,-1)
-            y[ap][1] = P[1] - P[2] - P[3] + bias4;
-            if (a.relu) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                y[ap][0] = max4(y[ap][0], z);
-                y[ap][1] = max4(y[ap][1], z);
-            }
-        }
-        if (a.pool_out) {
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {               // two pool windows per tile: rows (0,1) and (2,3)
-                const int r0 = oy + 2 * h2;
-                f32x4 v = y[2 * h2][0];
-                if (colok1) v = max4(v, y[2 * h2][1]);
-                if (r0 + 1 < a.H) {
-                    v = max4(v, y[2 * h2 + 1][0]);
-                    if (colok1) v = max4(v, y[2 * h2 + 1][1]);
-                }
-                const int off = (((r0 >> 1) * Wo + (ox >> 1)) * a.cout) * 4 + cbyte;
-                buf_store4(dst, v, (r0 < a.H && colok0) ? off : 0x7fffffff);
-            }
-        } else {
-#pragma unroll
-            for (int ap = 0; ap < 4; ++ap) {
-                const int off = (((oy + ap) * a.W + ox) * a.cout) * 4 + cbyte;
-                const bool rowok = oy + ap < a.H;
-                buf_store4(dst, y[ap][0], (rowok && colok0) ? off : 0x7fffffff);
-                buf_store4(dst, y[ap][1], (rowok && colok1) ? off + a.cout * 4 : 0x7fffffff);
-            }
+    epilogue();
+    if constexpr (DIAG == 3) {
+        phase[3] = __builtin_amdgcn_s_memrealtime();
+        if (a.dbg && lane_now() == 0) {     // [block][wave][4 stamps], then [block] hardware ids
+            unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wj) * 4;
+            d[0] = phase[0]; d[1] = phase[1]; d[2] = phase[2]; d[3] = phase[3];
+            if (wj == 0) a.dbg[(size_t)gridDim.x * 16 + blockIdx.x] =
+                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
         }
     }
 }
@@ -404,10 +499,30 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     a.xcd_order = order_env;
     const dim3 g((unsigned)blocks);
     static const int diag_env = getenv("ADAIN_W4_DIAG") ? atoi(getenv("ADAIN_W4_DIAG")) : 0;
-    if (a.dbg && diag_env == 2 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 2>), g, dim3(256), 0, s, a);
-    else if (a.dbg && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 1>), g, dim3(256), 0, s, a);
-    else if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X>), g, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a);
+    // persistent form (default) whenever the launch has at least two tiles per resident workgroup; ADAIN_W4_PERSIST = largest
+    // cin it is used for (0 = never: one tile per workgroup).  +2-3 % on most layer shapes, +1.1 % on the config-2 step.
+    static const int persist_env = getenv("ADAIN_W4_PERSIST") ? atoi(getenv("ADAIN_W4_PERSIST")) : 1 << 20;
+    static const int prio_env = getenv("ADAIN_W4_PRIO") ? atoi(getenv("ADAIN_W4_PRIO")) : 1;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("conv3x3_wino4: device query failed"); return -1; }
+        cus = prop.multiProcessorCount;
+    }
+    long long pgrid = 2LL * cus;
+    pgrid -= pgrid % 8;
+    const bool persist = !a.dbg && a.cin <= persist_env && a.cin >= 2 * W4_KR && pgrid >= 8 && blocks >= 2 * pgrid;
+    const int items = (int)blocks;
+    if (persist) {
+        const dim3 pg((unsigned)pgrid);
+        if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true>), pg, dim3(256), 0, s, a, items, prio_env);
+        else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, true>), pg, dim3(256), 0, s, a, items, prio_env);
+    } else if (a.dbg && diag_env == 2 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 2>), g, dim3(256), 0, s, a, items, 0);
+    else if (a.dbg && diag_env == 3 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 3>), g, dim3(256), 0, s, a, items, 0);
+    else if (a.dbg && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 1>), g, dim3(256), 0, s, a, items, 0);
+    else if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X>), g, dim3(256), 0, s, a, items, 0);
+    else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a, items, 0);
     return check_launch("conv3x3_wino4");
 }
 
