@@ -42,6 +42,19 @@ int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s);
 // conv_wino.hip
 int launch_pack_wino(const float* w_oihw, float* packed, int cin, int cout, hipStream_t s);
 int launch_conv3x3_wino(const ConvArgs& a, int src_mode, int mh, hipStream_t s);   // mh: kernel form (1, 2: V image in LDS; 3: register A; 4: persistent)
+// Compute units of the current device (cached per device id; 0 on failure).  Sizes the persistent kernels' grids.
+inline int device_cu_count() {
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 // conv_wino4.hip: F(4,3) x F(2,3) form (its own packed-weight layout, 24 floats per weight pair)
 int launch_pack_wino4(const float* w_oihw, float* packed, int cin, int cout, hipStream_t s);
 int launch_conv3x3_wino4(const ConvArgs& a, int src_mode, hipStream_t s);

@@ -445,13 +445,8 @@ int launch_conv3x3_wino3(const ConvArgs& a0, int src_mode, hipStream_t s) {
     a.tiles_y = (a.H + 3) / 4;
     const long long items = (long long)a.tiles_x * a.tiles_y * (a.cout / 64) * a.n;
     if (items <= 0 || items > 0x7fffffffLL) { set_error("conv3x3_wino3: bad tile count %lld", items); return -1; }
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("conv3x3_wino3: device query failed"); return -1; }
-        cus = prop.multiProcessorCount;
-    }
+    const int cus = device_cu_count();
+    if (cus <= 0) { set_error("conv3x3_wino3: device query failed"); return -1; }
     long long grid = 2LL * cus;                          // two workgroups per CU (launch bounds), a multiple of the 8 XCDs
     static const int grid_env = getenv("ADAIN_W3_GRID") ? atoi(getenv("ADAIN_W3_GRID")) : 0;       // debugging aid
     if (grid_env > 0) grid = grid_env;

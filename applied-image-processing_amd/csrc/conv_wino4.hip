@@ -503,13 +503,8 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     // cin it is used for (0 = never: one tile per workgroup).  +2-3 % on most layer shapes, +1.1 % on the config-2 step.
     static const int persist_env = getenv("ADAIN_W4_PERSIST") ? atoi(getenv("ADAIN_W4_PERSIST")) : 1 << 20;
     static const int prio_env = getenv("ADAIN_W4_PRIO") ? atoi(getenv("ADAIN_W4_PRIO")) : 1;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("conv3x3_wino4: device query failed"); return -1; }
-        cus = prop.multiProcessorCount;
-    }
+    const int cus = device_cu_count();
+    if (cus <= 0) { set_error("conv3x3_wino4: device query failed"); return -1; }
     long long pgrid = 2LL * cus;
     pgrid -= pgrid % 8;
     const bool persist = !a.dbg && a.cin <= persist_env && a.cin >= 2 * W4_KR && pgrid >= 8 && blocks >= 2 * pgrid;
