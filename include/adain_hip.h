@@ -131,18 +131,20 @@ int adain_conv3x3(const float* in_nhwc, float* out_nhwc, const float* packed_w, 
                   int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out, int variant,
                   adain_stream_t stream);
 
-/* Winograd F(2x2,3x3) form of the same layer (2.25x fewer multiplies; fp32 rounding error ~2x the direct form's),
- * used by adain_encode / adain_decode for the cin >= 128 layers.  Takes its own packing (16 floats per
- * (cin, cout) pair).  src_mode DIRECT or UP2X; cin % 8 == 0, cout % 64 == 0. */
+/* Winograd forms of the same layer (adain_encode / adain_decode use form 5 for every generic 3x3 layer).
+ *   form 5: F(4,3) x F(2,3), 4 x 2 output tiles, 3 multiplies per output instead of 9 (fp32 rounding error ~5x the direct
+ *           form's, ~1e-6 relative per layer); its own packing, 24 floats per (cin, cout) pair (adain_conv3x3_wino4_pack);
+ *           cin % 16 == 0, cout % 32 == 0; persistent kernel when the launch has >= 2 tiles per resident workgroup;
+ *   forms 1-4: F(2x2,3x3), 4 multiplies per output; packing of 16 floats per pair (adain_conv3x3_wino_pack); cout % 64 == 0;
+ *           3: A operand transformed in registers (cin % 16 == 0), 4: its persistent form (cin >= 32), 1 / 2: transformed
+ *           input staged in LDS (cin % 8 == 0), 1 or 2 32-tile M-tiles per workgroup.
+ * src_mode DIRECT or UP2X; relu / pool_out as for adain_conv3x3. */
 size_t adain_conv3x3_wino_packed_floats(int cin, int cout);
 int adain_conv3x3_wino_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
-/* F(4,3) x F(2,3) form (form = 5 of adain_conv3x3_wino): its own packed layout, 24 floats per (cin, cout) pair */
 size_t adain_conv3x3_wino4_packed_floats(int cin, int cout);
 int adain_conv3x3_wino4_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
 int adain_conv3x3_wino(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,
-                       int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out,
-                       int form /* 3: A operand transformed in registers (default of encode/decode; cin % 16 == 0); 1 / 2: transformed
-                                    input staged in LDS, 1 or 2 32-tile M-tiles per workgroup */,
+                       int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out, int form,
                        adain_stream_t stream);
 
 #ifdef __cplusplus
