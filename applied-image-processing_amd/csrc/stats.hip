@@ -169,30 +169,48 @@ __global__ __launch_bounds__(256) void adain_blend_kernel(const float* __restric
                                                           const float* __restrict__ pmap, int pmap_n,
                                                           float* __restrict__ out, size_t total4) {
 #pragma clang fp contract(off)
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t e = i * 4;
+    // 32-bit index arithmetic (the launcher checks total < 2^31) and, for NHWC, one b128 load per statistic: the four
+    // elements of a quad are four consecutive channels of one pixel
+    const unsigned per_img = (unsigned)c * (unsigned)hw;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total4; i += gridDim.x * blockDim.x) {
+        const unsigned e = i * 4u;
         const f32x4 v = *(const f32x4*)(x + e);
         f32x4 r;
-        const size_t per_img = (size_t)c * hw;
-        const int img = (int)(e / per_img);
-        const size_t rem = e - (size_t)img * per_img;
-        const int simg = style_n == 1 ? 0 : img;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int ch, pix;
-            if (NHWC) { ch = (int)(rem % c) + k; pix = (int)(rem / c); }
-            else      { ch = (int)((rem + k) / hw); pix = (int)((rem + k) % hw); }
-            const float mc = c_mean[(size_t)img * c + ch], sc = c_std[(size_t)img * c + ch];
-            const float ms = s_mean[(size_t)simg * c + ch], ss = s_std[(size_t)simg * c + ch];
-            const float nrm = (v[k] - mc) / sc;
-            const float t = nrm * ss + ms;
+        const unsigned img = e / per_img;
+        const unsigned rem = e - img * per_img;
+        const unsigned simg = style_n == 1 ? 0u : img;
+        if (NHWC) {
+            const unsigned pix = rem / (unsigned)c, ch = rem - pix * (unsigned)c;
+            const f32x4 mc = *(const f32x4*)(c_mean + img * c + ch), sc = *(const f32x4*)(c_std + img * c + ch);
+            const f32x4 ms = *(const f32x4*)(s_mean + simg * c + ch), ss = *(const f32x4*)(s_std + simg * c + ch);
             float w1 = alpha, w2 = one_minus_alpha;
             if (pmap) {
-                const float p = pmap[(size_t)(pmap_n == 1 ? 0 : img) * hw + pix];
+                const float p = pmap[(pmap_n == 1 ? 0u : img) * (unsigned)hw + pix];
                 w1 = 1.0f - p;
                 w2 = p;
             }
-            r[k] = t * w1 + v[k] * w2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float nrm = (v[k] - mc[k]) / sc[k];
+                const float t = nrm * ss[k] + ms[k];
+                r[k] = t * w1 + v[k] * w2;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned ch = (rem + k) / (unsigned)hw, pix = (rem + k) - ch * (unsigned)hw;
+                const float mc = c_mean[img * c + ch], sc = c_std[img * c + ch];
+                const float ms = s_mean[simg * c + ch], ss = s_std[simg * c + ch];
+                const float nrm = (v[k] - mc) / sc;
+                const float t = nrm * ss + ms;
+                float w1 = alpha, w2 = one_minus_alpha;
+                if (pmap) {
+                    const float p = pmap[(pmap_n == 1 ? 0u : img) * (unsigned)hw + pix];
+                    w1 = 1.0f - p;
+                    w2 = p;
+                }
+                r[k] = t * w1 + v[k] * w2;
+            }
         }
         *(f32x4*)(out + e) = r;
     }
@@ -206,8 +224,9 @@ int launch_adain_blend_ex(const float* content, int nhwc, int n, int c, int hw, 
     if (pmap && pmap_n != 1 && pmap_n != n) { set_error("adain_blend: pmap batch %d must be 1 or %d", pmap_n, n); return -1; }
     const size_t total = (size_t)n * c * hw;
     if (nhwc ? (c & 3) : (total & 3)) { set_error("adain_blend: element count / channels must be a multiple of 4"); return -1; }
+    if (total >= 0x7fffffffULL) { set_error("adain_blend: more than 2^31 elements per call"); return -1; }
     const size_t total4 = total / 4;
-    const unsigned blocks = (unsigned)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+    const unsigned blocks = (unsigned)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
     if (nhwc)
         hipLaunchKernelGGL(adain_blend_kernel<true>, dim3(blocks), dim3(256), 0, s, content, c, hw, c_mean, c_std, s_mean, s_std,
                            style_n, alpha, one_minus_alpha, pmap, pmap_n, out, total4);
