@@ -76,9 +76,16 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
-// DIAG (tools/wino4_probe.py, tools/wino4_phase_probe.py; not the product path): 1 = a shader-clock stamp per 8-MFMA double step of
-// the first 32 workgroups, 2 = the same with LDS padded to one workgroup per CU, 3 = four s_memrealtime phase stamps per wave
-// (entry, main-loop start / end, exit).
+// DIAG (not the product path; selected by ADAIN_W4_DIAG when a stamp buffer is set, tools/wino4_probe.py, tools/wino4_phase_probe.py,
+// tools/probes/diag_ab.py):
+//   1 = a shader-clock stamp per 8-MFMA double step of the first 32 workgroups, 2 = the same with LDS padded to one workgroup per
+//   CU, 3 = four s_memrealtime phase stamps per wave (entry, main-loop start / end, exit);
+//   timing-only ablations of the one-tile form (wrong results by construction; A/B against the product kernel, two workgroups
+//   per CU, 256->256 at 256^2 / 64->64 at 1024^2): 5 = no input transform at all (+16 %), 6 = no patch reads, arithmetic on stale
+//   registers (+16 %: the LDS reads are the transform's whole cost), 9 = ds_read_b32 instead of b128 (+5 %), 7 = no stage
+//   barrier (+2 %), 8 = no halo loads or stores (+8 / +10 %), 10 = no halo loads (+5 / +8 %), 11 = no halo stores (+3 %),
+//   12 = (correct results) 12-slot weight ring, a whole chunk ahead (+1 %).  In a bare MFMA loop neither LDS reads nor streaming
+//   weight loads cost the matrix pipe anything (tools/probes/mfma_chain_probe.hip), so these are waits, not port conflicts.
 // PERSIST: a workgroup walks a list of tiles (grid = 2 per CU; XCD x owns a contiguous range of the tile list, channel tile
 // fastest) instead of one: the next tile's first halo stage is loaded during the current tile's last stages and its first
 // weight fragments replace the ring's run-off loads, so a tile starts with an LDS write + barrier + transform instead of a cold
@@ -165,10 +172,12 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     };
 
     // ---- weights: one b128 fragment per step (row position r), ring slot = r, loaded 5 steps ahead ---------------------------
-    f32x4 bq[6];
+    // RING12 (experiment, DIAG 12): two chunks of weight slots - a chunk's six fragments are requested during the previous chunk
+    constexpr bool RING12 = DIAG == 12;
+    f32x4 bq[RING12 ? 12 : 6];
     int wso = ((ct * 4 + wj) * nch) * 6144;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bq[r] = buf_load4(wsr, wvo, wso + r * 1024);
+    for (int r = 0; r < (RING12 ? 6 : 4); ++r) bq[r] = buf_load4(wsr, wvo, wso + r * 1024);
 
     f32x16 acc[6];
 #pragma unroll
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         };
         auto rows_5 = [&]() { o5 = 4.f * f[1] + (f[5] - 5.f * f[3]); };
 
-        f32x4 aq[6], q2, q3, t1, t2, t3, d31;
+        f32x4 aq[6], t1, t2, t3, d31;
         int xaddr = 0;          // this lane's patch origin in the halo image (floats), rebuilt at the start of every chunk
         auto xf_addr = [&]() {
             const int l = lane_now(), li = l & 31, lh = l >> 5;
@@ -300,6 +309,15 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 dB[k] = *(const f32x4*)(rb + xaddr + ((a0 + k) * W4_HALO_W + cB) * W4_RSTR);
             }
         };
+        // one patch read (read index i = 0..5 of rows a0..a0+2: i / 2 = row, i & 1 = column cA / cB)
+        auto xf_read1 = [&](const float* rb, int a0, auto II) {
+            constexpr int i = decltype(II)::value, k = i / 2;
+            if constexpr (DIAG == 9) {      // timing-only: the same number of LDS instructions, a quarter of the bytes
+                if constexpr ((i & 1) == 0) dA[k][0] = *(const float*)(rb + xaddr + ((a0 + k) * W4_HALO_W + cA) * W4_RSTR);
+                else dB[k][0] = *(const float*)(rb + xaddr + ((a0 + k) * W4_HALO_W + cB) * W4_RSTR);
+            } else if constexpr ((i & 1) == 0) dA[k] = *(const f32x4*)(rb + xaddr + ((a0 + k) * W4_HALO_W + cA) * W4_RSTR);
+            else dB[k] = *(const f32x4*)(rb + xaddr + ((a0 + k) * W4_HALO_W + cB) * W4_RSTR);
+        };
         int saddr = 0;
         auto st_addr = [&]() {
             const int t = lane_now() | (wj << 6);
@@ -311,8 +329,9 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         // 412 cycles per 4 instead of 256 + issue overheads), and left to itself the scheduler builds exactly those chains.
         // XF: transform the next chunk's patches meanwhile; ST: the last third also writes the staged halo registers to LDS;
         // LD: the halo loads two stages ahead.  Weight ring: slot = row position, refilled as soon as its MFMAs have issued.
-        auto chunk = [&](const float* nsrc, auto XFC, auto STC, auto LDC, int raw_soff, float* store_to, int wnext) {
+        auto chunk = [&](const float* nsrc, auto XFC, auto STC, auto LDC, int raw_soff, float* store_to, int wnext, auto PARC) {
             constexpr bool do_xf = decltype(XFC)::value, st = decltype(STC)::value, ld = decltype(LDC)::value;
+            constexpr int par = RING12 ? decltype(PARC)::value : 0;
             auto half = [&](auto HH) {
                 constexpr int h = decltype(HH)::value;          // 0..23: mini-step m = h / 2 (d = m / 4, s = m % 4), b = second MFMA
                 constexpr int m = h / 2, b = h & 1, d = m / 4, sidx = m & 3, r = 2 * d + b;
@@ -321,9 +340,11 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                     if (lane_now() == 0 && nlog < 96) steplog[WJ * 96 + nlog] = tnow;
                     ++nlog;
                 }
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[r][sidx], aq[r][sidx], acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[6 * par + r][sidx], aq[r][sidx], acc[r], 0, 0, 0);
                 // ---- weight ring: (this chunk) slots 4, 5 at mini-steps 0, 1; (next chunk) slots 0, 1 at 4, 5; slots 2, 3 at 8, 9 ----
-                if constexpr (b == 0) {
+                if constexpr (RING12) {
+                    if constexpr (b == 0 && m < 6) bq[6 * (1 - par) + m] = buf_load4(wsr, wvo, wnext + m * 1024);
+                } else if constexpr (b == 0) {
                     if constexpr (m == 0) bq[4] = buf_load4(wsr, wvo, wso + 4 * 1024);
                     if constexpr (m == 1) bq[5] = buf_load4(wsr, wvo, wso + 5 * 1024);
                     if constexpr (m == 4) bq[0] = buf_load4(wsr, wvo, wnext);
@@ -332,29 +353,31 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                     if constexpr (m == 9) bq[3] = buf_load4(wsr, wvo, wnext + 3 * 1024);
                 }
                 // ---- halo loads two stages ahead, in the first two thirds of the chunk (regions 5, 7, 9, 11, 13, 15) ----
-                if constexpr (ld && b == 1 && h >= 5 && h <= 15) {
+                if constexpr (ld && DIAG != 10 && b == 1 && h >= 5 && h <= 15) {      // DIAG 10: timing-only, no halo loads (stale stores)
                     constexpr int k = (h - 5) / 2;
                     rawreg[k] = buf_load4(src, roff[k], raw_soff);
                 }
                 // ---- input transform of the next chunk ----
-                if constexpr (do_xf) {
+                // (one LDS instruction per region: six patch reads behind one MFMA hold the wave for ~200 cycles while the LDS
+                // queue takes them - timing-only builds without the patch reads ran 16 % faster, without the transform's
+                // arithmetic no faster than that)
+                if constexpr (do_xf && DIAG != 5) {
                     if constexpr (h == 0) xf_addr();
-                    if constexpr (h == 1) xf_read3(nsrc, 0);
-                    if constexpr (h == 4) xf_cols(0);
-                    if constexpr (h == 5) xf_read3(nsrc, 3);
-                    if constexpr (h == 8) xf_cols(3);
-                    if constexpr (h == 9) aq[0] = 4.f * f[0] + (f[4] - 5.f * f[2]);                 // fragments 0, 1: dead since mini-step 3
-                    if constexpr (h == 10) { t1 = f[4] - 4.f * f[2]; t2 = f[3] - 4.f * f[1]; }
-                    if constexpr (h == 11) { aq[1] = t1 + t2; q2 = t1 - t2; }
-                    if constexpr (h == 12) { t3 = f[4] - f[2]; d31 = f[3] - f[1]; }
-                    if constexpr (h == 13) { q3 = t3 + 2.f * d31; o4 = t3 - 2.f * d31; }
-                    if constexpr (h == 14) o5 = 4.f * f[1] + (f[5] - 5.f * f[3]);
-                    if constexpr (h == 16) { aq[2] = q2; aq[3] = q3; }                              // dead since mini-step 7
+                    if constexpr (h >= 1 && h <= 6 && DIAG != 6) xf_read1(nsrc, 0, std::integral_constant<int, h - 1>{});
+                    if constexpr (h == 10) xf_cols(0);                                             // four regions after the last read
+                    if constexpr (h >= 11 && h <= 16 && DIAG != 6) xf_read1(nsrc, 3, std::integral_constant<int, h - 11>{});
+                    if constexpr (h == 20) xf_cols(3);
+                    if constexpr (h == 21) { aq[0] = 4.f * f[0] + (f[4] - 5.f * f[2]); t1 = f[4] - 4.f * f[2]; t2 = f[3] - 4.f * f[1]; }   // fragments 0..3: dead since region 15
+                    if constexpr (h == 22) { aq[1] = t1 + t2; aq[2] = t1 - t2; t3 = f[4] - f[2]; d31 = f[3] - f[1]; }
+                    if constexpr (h == 23) { aq[3] = t3 + 2.f * d31; o4 = t3 - 2.f * d31; o5 = 4.f * f[1] + (f[5] - 5.f * f[3]); }
                 }
                 // ---- halo store of the stage loaded one stage ago ----
-                if constexpr (st) {
+                if constexpr (st && DIAG != 8 && DIAG != 11) {
                     if constexpr (h == 16) st_addr();
                     if constexpr (h >= 17 && h <= 22) *(f32x4*)(store_to + saddr + (h - 17) * 64 * W4_RSTR) = rawreg[h - 17];
+                }
+                if constexpr (st && DIAG == 11) {      // timing-only: halo loads kept alive without the LDS stores
+                    if constexpr (h >= 17 && h <= 22) asm volatile("" ::"v"(rawreg[h - 17]));
                 }
                 if constexpr (do_xf && h == 23) { aq[4] = o4; aq[5] = o5; }
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // the MFMA first, everything else behind it
@@ -365,6 +388,8 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         };
         constexpr std::true_type T{};
         constexpr std::false_type F{};
+        constexpr std::integral_constant<int, 0> P0{};
+        constexpr std::integral_constant<int, 1> P1{};
 
         // ---- prologue --------------------------------------------------------------------------------------------------------------
         raw_load(0);
@@ -382,12 +407,12 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
             for (int s = 0; s + 1 < nst; ++s) {
                 const float* cur = Rs + (s & 1) * W4_RBUF;
                 float* nxt = Rs + ((s + 1) & 1) * W4_RBUF;
-                chunk(cur + 8, T, T, F, 0, nxt, wso + 6144);                // channels 0..7; prepares 8..15; writes the next stage's halo
-                __syncthreads();
-                chunk(nxt, T, F, T, (s + 2) * W4_KR * 4, nullptr, wso + 6144);      // channels 8..15; prepares the next stage; loads two stages ahead
+                chunk(cur + 8, T, T, F, 0, nxt, wso + 6144, P0);                // channels 0..7; prepares 8..15; writes the next stage's halo
+                if constexpr (DIAG != 7) __syncthreads();
+                chunk(nxt, T, F, T, (s + 2) * W4_KR * 4, nullptr, wso + 6144, P1);      // channels 8..15; prepares the next stage; loads two stages ahead
             }
-            chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, wso + 6144);
-            chunk(Rs, F, F, F, 0, nullptr, wso + 6144);
+            chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, wso + 6144, P0);
+            chunk(Rs, F, F, F, 0, nullptr, wso + 6144, P1);
             if constexpr (DIAG == 3) phase[2] = __builtin_amdgcn_s_memrealtime();
         } else {
             int ntile = 0;
@@ -413,13 +438,13 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 for (int s = 0; s + 1 < nst; ++s) {
                     const float* cur = Rs + (s & 1) * W4_RBUF;
                     float* nxt = Rs + ((s + 1) & 1) * W4_RBUF;
-                    chunk(cur + 8, T, T, F, 0, nxt, wso + 6144);
+                    chunk(cur + 8, T, T, F, 0, nxt, wso + 6144, P0);
                     __syncthreads();
-                    chunk(nxt, T, F, T, s == nst - 2 ? 0 : (s + 2) * W4_KR * 4, nullptr, wso + 6144);
+                    chunk(nxt, T, F, T, s == nst - 2 ? 0 : (s + 2) * W4_KR * 4, nullptr, wso + 6144, P1);
                     if (s == nst - 3) next_halo();
                 }
-                chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, wso + 6144);
-                chunk(Rs, F, F, F, 0, nullptr, wso_next);      // the ring's look-ahead continues in the next tile's weights
+                chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, wso + 6144, P0);
+                chunk(Rs, F, F, F, 0, nullptr, wso_next, P1);      // the ring's look-ahead continues in the next tile's weights
                 wso = wso_next;
                 __syncthreads();
                 epilogue();                                     // of (ct, img, tx0, ty0); also writes the next tile's first halo stage
@@ -515,6 +540,14 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
         else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, true>), pg, dim3(256), 0, s, a, items, prio_env);
     } else if (a.dbg && diag_env == 2 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 2>), g, dim3(256), 0, s, a, items, 0);
     else if (a.dbg && diag_env == 3 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 3>), g, dim3(256), 0, s, a, items, 0);
+    else if (a.dbg && diag_env == 5 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 5>), g, dim3(256), 0, s, a, items, 0);
+    else if (a.dbg && diag_env == 6 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 6>), g, dim3(256), 0, s, a, items, 0);
+    else if (a.dbg && diag_env == 7 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 7>), g, dim3(256), 0, s, a, items, 0);
+    else if (a.dbg && diag_env == 8 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 8>), g, dim3(256), 0, s, a, items, 0);
+    else if (a.dbg && diag_env == 12 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 12>), g, dim3(256), 0, s, a, items, 0);
+    else if (a.dbg && diag_env == 10 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 10>), g, dim3(256), 0, s, a, items, 0);
+    else if (a.dbg && diag_env == 11 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 11>), g, dim3(256), 0, s, a, items, 0);
+    else if (a.dbg && diag_env == 9 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 9>), g, dim3(256), 0, s, a, items, 0);
     else if (a.dbg && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 1>), g, dim3(256), 0, s, a, items, 0);
     else if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X>), g, dim3(256), 0, s, a, items, 0);
     else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a, items, 0);

@@ -114,6 +114,65 @@ static void run_loads(int blocks_per_cu, unsigned bytes) {
     hipFree(out); hipFree(w); hipFree(cyc);
 }
 
+// MFMA stream with NR ds_read_b128 per 24 MFMA-equivalents (4096 flop each), two waves per SIMD: 32x32x2 (16 acc registers in
+// and out per instruction) against 16x16x4 (4 in / out, twice as many instructions): does LDS return traffic slow the matrix pipe?
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+template <int NR, bool SMALL>
+__global__ __launch_bounds__(256, 2) void mfma_lds(float* out, unsigned long long* cyc, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[16384];
+    for (int i = threadIdx.x; i < 16384; i += 256) lds[i] = i * 1e-4f;
+    __syncthreads();
+    f32x16 acc[6];
+    for (int k = 0; k < 6; ++k)
+        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+    f32x4v d[12];
+    for (int i = 0; i < 12; ++i) d[i] = f32x4v{1.f, 2.f, 3.f, 4.f};
+    const int lane_off = (threadIdx.x & 63) * 20 + (threadIdx.x >> 6) * 4000;
+    float a = threadIdx.x * 0.001f + 1.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int h = 0; h < 24; ++h) {
+            const int r = h % 6;
+            if constexpr (SMALL) {
+                f32x4v* q = (f32x4v*)&acc[r];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) q[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, d[h % 12][t & 3], q[t], 0, 0, 0);
+            } else {
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d[h % 12][h & 3], acc[r], 0, 0, 0);
+            }
+            if (h < NR) d[(h + 6) % 12] = *(const f32x4v*)(lds + lane_off + h * 320);
+            __builtin_amdgcn_sched_group_barrier(0x008, SMALL ? 4 : 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float sum = 0.f;
+    for (int k = 0; k < 6; ++k)
+        for (int e = 0; e < 16; ++e) sum += acc[k][e];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int NR, bool SMALL>
+static void run_lds() {
+    float* out;
+    unsigned long long* cyc;
+    const int blocks = 512;
+    hipMalloc(&out, blocks * 256 * sizeof(float));
+    hipMalloc(&cyc, blocks * sizeof(unsigned long long));
+    const int iters = 300;
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((mfma_lds<NR, SMALL>), dim3(blocks), dim3(256), 0, 0, out, cyc, iters);
+    hipDeviceSynchronize();
+    unsigned long long h[4096];
+    hipMemcpy(h, cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double sum = 0;
+    for (int i = 0; i < blocks; ++i) sum += (double)h[i];
+    printf("%s, %2d ds_read_b128 per 24 MFMA-equivalents, 2 waves per SIMD: %.0f cycles per 24 per wave (ideal 3072)\n", SMALL ? "16x16x4" : "32x32x2", NR,
+           sum / blocks / iters);
+    hipFree(out); hipFree(cyc);
+}
+
 template <int K>
 static void run_ops() {
     float *out, *in;
@@ -160,6 +219,8 @@ int main() {
         run<1>(w); run<2>(w); run<3>(w); run<4>(w); run<6>(w);
     }
     run_ops<1>(); run_ops<2>(); run_ops<6>();
+    run_lds<0, false>(); run_lds<6, false>(); run_lds<12, false>(); run_lds<24, false>();
+    run_lds<0, true>(); run_lds<6, true>(); run_lds<12, true>(); run_lds<24, true>();
     for (int bpc = 1; bpc <= 2; ++bpc) {
         run_loads<0>(bpc, 1u << 20); run_loads<1>(bpc, 1u << 20); run_loads<2>(bpc, 1u << 20); run_loads<4>(bpc, 1u << 20);
         run_loads<2>(bpc, 6u << 20); run_loads<4>(bpc, 6u << 20); run_loads<2>(bpc, 64u << 20);
