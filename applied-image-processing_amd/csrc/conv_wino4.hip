@@ -84,7 +84,8 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
 //   per CU, 256->256 at 256^2 / 64->64 at 1024^2): 5 = no input transform at all (+16 %), 6 = no patch reads, arithmetic on stale
 //   registers (+16 %: the LDS reads are the transform's whole cost), 9 = ds_read_b32 instead of b128 (+5 %), 7 = no stage
 //   barrier (+2 %), 8 = no halo loads or stores (+8 / +10 %), 10 = no halo loads (+5 / +8 %), 11 = no halo stores (+3 %),
-//   12 = (correct results) 12-slot weight ring, a whole chunk ahead (+1 %).  In a bare MFMA loop neither LDS reads nor streaming
+//   12 = (correct results) 12-slot weight ring, a whole chunk ahead (+1 %); a build that sent the halo straight to LDS
+//   (`buffer_load ... lds`, wrong image layout, no staging registers or ds_writes; since removed) measured +3 %.  In a bare MFMA loop neither LDS reads nor streaming
 //   weight loads cost the matrix pipe anything (tools/probes/mfma_chain_probe.hip), so these are waits, not port conflicts.
 // PERSIST: a workgroup walks a list of tiles (grid = 2 per CU; XCD x owns a contiguous range of the tile list, channel tile
 // fastest) instead of one: the next tile's first halo stage is loaded during the current tile's last stages and its first
