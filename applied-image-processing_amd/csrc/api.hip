@@ -317,6 +317,10 @@ int adain_warp_blend_u8(const uint8_t* cur, const uint8_t* prev, const float* fl
     if (!cur || !prev || !flow || !out) { set_error("warp_blend_u8: null pointer"); return ADAIN_EINVAL; }
     return launch_warp_blend_u8(cur, prev, flow, out, h, w, c, alpha, one_minus_alpha, (hipStream_t)stream);
 }
+int adain_resize_area_u8(const uint8_t* in, uint8_t* out, int n, int hi, int wi, int c, int ho, int wo, adain_stream_t stream) {
+    if (!in || !out) { set_error("resize_area_u8: null pointer"); return ADAIN_EINVAL; }
+    return launch_resize_area_u8(in, out, n, hi, wi, c, ho, wo, (hipStream_t)stream);
+}
 int adain_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, adain_stream_t stream) {
     if (!in || !out) { set_error("nhwc_to_nchw: null pointer"); return ADAIN_EINVAL; }
     return launch_nhwc_to_nchw(in, out, n, c, hw, (hipStream_t)stream);

@@ -84,6 +84,7 @@ int launch_mask_composite(const float* content, const float* stylized, const flo
 int launch_warp_blend_u8(const uint8_t* cur, const uint8_t* prev, const float* flow, uint8_t* out, int h, int w, int c,
                          float alpha, float one_minus_alpha, hipStream_t s);
 int launch_quantize_u8(const float* in_nchw, uint8_t* out_nhwc, int n, int c, int h, int w, hipStream_t s);
+int launch_resize_area_u8(const uint8_t* in, uint8_t* out, int n, int hi, int wi, int c, int ho, int wo, hipStream_t s);
 int launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, hipStream_t s);
 

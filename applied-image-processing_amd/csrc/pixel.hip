@@ -75,88 +75,137 @@ __global__ __launch_bounds__(256) void bicubic_minmax_kernel(const float* __rest
     }
 }
 
-// K2 (one block): global min/max, mean of the normalised map (fp64 sum, fixed order), final map in place.
-__global__ __launch_bounds__(1024) void strength_finish_kernel(float* __restrict__ p, int total, const float* __restrict__ part,
-                                                               int nparts, float offset, float prominence) {
-    __shared__ float shf[2];
-    __shared__ double shd[16];
-    const int tid = threadIdx.x;
-    if (tid == 0) {
+// K2 / K3: global min/max from K1's partials (every block re-reduces the <= 64 pairs in the same fixed order), then
+//   K2: per-block fp64 partial sums of the normalised map (fixed slice per block, fixed combine order);
+//   K3: mean = (sum of the partials in index order) / total, final map in place.
+// Both are multi-block: at a 256 x 256 map the former single 1024-thread block was a serial 15-20 us tail per frame.
+__device__ __forceinline__ void strength_minmax(const float* __restrict__ part, int nparts, float* shf) {
+    if (threadIdx.x == 0) {
         float lo = INFINITY, hi = -INFINITY;
         for (int i = 0; i < nparts; ++i) { lo = fminf(lo, part[i * 2]); hi = fmaxf(hi, part[i * 2 + 1]); }
         shf[0] = lo; shf[1] = hi;
     }
     __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void strength_sum_kernel(const float* __restrict__ p, int total, const float* __restrict__ part,
+                                                           int nparts, double* __restrict__ psum) {
+    __shared__ float shf[2];
+    __shared__ double shd[4];
+    strength_minmax(part, nparts, shf);
     const float lo = shf[0], hi = shf[1];
-    if (!(hi > lo)) {   // constant map -> zeros (test.py:141-143)
-        for (int i = tid; i < total; i += 1024) p[i] = 0.f;
-        return;
-    }
-    const float range = hi - lo;
     double s = 0;
-    for (int i = tid; i < total; i += 1024) s += (double)((p[i] - lo) / range);
+    if (hi > lo) {
+        const float range = hi - lo;
+        // block b owns the contiguous slice [b * per, (b + 1) * per): the partition depends only on (total, gridDim)
+        const int per = (total + gridDim.x - 1) / gridDim.x;
+        const int i0 = blockIdx.x * per, i1 = min(i0 + per, total);
+        for (int i = i0 + threadIdx.x; i < i1; i += 256) s += (double)((p[i] - lo) / range);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((tid & 63) == 0) shd[tid >> 6] = s;
+    if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
     __syncthreads();
-    double ts = 0;
-    for (int w = 0; w < 16; ++w) ts += shd[w];
-    const float mean = (float)(ts / total);
-    const float cap = 1.0f - offset;
-    for (int i = tid; i < total; i += 1024) {
-        const float v = (p[i] - lo) / range - mean;
-        const float sg = 1.0f / (1.0f + expf(-prominence * v));
-        p[i] = fminf(sg, cap);
+    if (threadIdx.x == 0) psum[blockIdx.x] = (shd[0] + shd[1]) + (shd[2] + shd[3]);
+}
+
+__global__ __launch_bounds__(256) void strength_apply_kernel(float* __restrict__ p, int total, const float* __restrict__ part,
+                                                             int nparts, const double* __restrict__ psum, int nsum, float offset,
+                                                             float prominence) {
+    __shared__ float shf[3];
+    strength_minmax(part, nparts, shf);
+    if (threadIdx.x == 0) {
+        double ts = 0;
+        for (int i = 0; i < nsum; ++i) ts += psum[i];
+        shf[2] = (float)(ts / total);
     }
+    __syncthreads();
+    const float lo = shf[0], hi = shf[1], mean = shf[2];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    if (!(hi > lo)) {   // constant map -> zeros (test.py:141-143)
+        p[i] = 0.f;
+        return;
+    }
+    const float range = hi - lo, cap = 1.0f - offset;
+    const float v = (p[i] - lo) / range - mean;
+    const float sg = 1.0f / (1.0f + expf(-prominence * v));
+    p[i] = fminf(sg, cap);
 }
 
 constexpr int SM_BLOCKS = 64;
-size_t strength_map_workspace_bytes(int, int) { return SM_BLOCKS * 2 * sizeof(float); }
+size_t strength_map_workspace_bytes(int, int) { return SM_BLOCKS * 2 * sizeof(float) + SM_BLOCKS * sizeof(double); }
 
 int launch_strength_map(const float* depth, int h0, int w0, int hc, int wc, float offset, float prominence, float* pmap,
                         void* workspace, size_t ws_bytes, hipStream_t s) {
     if (h0 < 1 || w0 < 1 || hc < 1 || wc < 1) { set_error("strength_map: bad shape"); return -1; }
+    if ((size_t)hc * wc >= 0x7fffffffULL || (size_t)h0 * w0 >= 0x7fffffffULL) { set_error("strength_map: map too large"); return -1; }
     if (!workspace || ws_bytes < strength_map_workspace_bytes(hc, wc)) { set_error("strength_map: workspace too small"); return -1; }
     const int total = hc * wc;
     int blocks = (total + 255) / 256;
     if (blocks > SM_BLOCKS) blocks = SM_BLOCKS;
-    hipLaunchKernelGGL(bicubic_minmax_kernel, dim3(blocks), dim3(256), 0, s, depth, h0, w0, hc, wc, pmap, (float*)workspace);
-    hipLaunchKernelGGL(strength_finish_kernel, dim3(1), dim3(1024), 0, s, pmap, total, (const float*)workspace, blocks, offset, prominence);
+    float* part = (float*)workspace;
+    double* psum = (double*)(part + SM_BLOCKS * 2);
+    hipLaunchKernelGGL(bicubic_minmax_kernel, dim3(blocks), dim3(256), 0, s, depth, h0, w0, hc, wc, pmap, part);
+    hipLaunchKernelGGL(strength_sum_kernel, dim3(blocks), dim3(256), 0, s, pmap, total, part, blocks, psum);
+    hipLaunchKernelGGL(strength_apply_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pmap, total, part, blocks, psum, blocks, offset,
+                       prominence);
     return check_launch("strength_map");
 }
 
 // ---- bilinear / nearest resize over `planes` independent [hi][wi] planes -------------------------------
-__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int hi,
-                                                              int wi, int ho, int wo, size_t total) {
-    const float sy = (float)hi / (float)ho, sx = (float)wi / (float)wo;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ox = (int)(i % wo);
-        const size_t r = i / wo;
-        const int oy = (int)(r % ho);
-        const size_t pl = r / ho;
-        const float ry = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.f), rx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.f);
-        const int y0 = min((int)ry, hi - 1), x0 = min((int)rx, wi - 1);
-        const int y1 = y0 + (y0 < hi - 1 ? 1 : 0), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
-        const float ly1 = fminf(fmaxf(ry - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(rx - (float)x0, 0.f), 1.f);
-        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-        const float* __restrict__ p = in + pl * (size_t)hi * wi;
-        const float top = lx0 * p[(size_t)y0 * wi + x0] + lx1 * p[(size_t)y0 * wi + x1];
-        const float bot = lx0 * p[(size_t)y1 * wi + x0] + lx1 * p[(size_t)y1 * wi + x1];
-        out[i] = ly0 * top + ly1 * bot;
+// Launch geometry of the row kernels: block = 64 x 4 threads, a thread owns 4 consecutive output pixels of one row
+// (blockIdx.y = row group, blockIdx.z = plane): no per-thread division, 32-bit offsets inside a plane, one b128 store per
+// thread when the row length is a multiple of 4 (scalar stores otherwise).  The index / weight arithmetic is ATen's.
+__device__ __forceinline__ void store_quad(float* __restrict__ row, int x, int wo, bool vec, const f32x4 v) {
+    if (vec) {
+        *(f32x4*)(row + x) = v;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (x + k < wo) row[x + k] = v[k];
     }
 }
 
-__global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __restrict__ in, float* __restrict__ out, int hi,
-                                                             int wi, int ho, int wo, size_t total) {
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int hi,
+                                                              int wi, int ho, int wo, int vec) {
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4, oy = blockIdx.y * 4 + threadIdx.y;
+    if (x >= wo || oy >= ho) return;
     const float sy = (float)hi / (float)ho, sx = (float)wi / (float)wo;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ox = (int)(i % wo);
-        const size_t r = i / wo;
-        const int oy = (int)(r % ho);
-        const size_t pl = r / ho;
-        const int y = min((int)floorf((float)oy * sy), hi - 1), x = min((int)floorf((float)ox * sx), wi - 1);
-        out[i] = in[pl * (size_t)hi * wi + (size_t)y * wi + x];
+    const float ry = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)ry, hi - 1), y1 = y0 + (y0 < hi - 1 ? 1 : 0);
+    const float ly1 = fminf(fmaxf(ry - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
+    const float* __restrict__ p0 = in + (size_t)blockIdx.z * hi * wi + (unsigned)(y0 * wi);
+    const float* __restrict__ p1 = in + (size_t)blockIdx.z * hi * wi + (unsigned)(y1 * wi);
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ox = min(x + k, wo - 1);
+        const float rx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.f);
+        const int x0 = min((int)rx, wi - 1), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+        const float lx1 = fminf(fmaxf(rx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
+        const float top = lx0 * p0[x0] + lx1 * p0[x1];
+        const float bot = lx0 * p1[x0] + lx1 * p1[x1];
+        r[k] = ly0 * top + ly1 * bot;
     }
+    store_quad(out + ((size_t)blockIdx.z * ho + oy) * wo, x, wo, vec, r);
+}
+
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __restrict__ in, float* __restrict__ out, int hi,
+                                                             int wi, int ho, int wo, int vec) {
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4, oy = blockIdx.y * 4 + threadIdx.y;
+    if (x >= wo || oy >= ho) return;
+    const float sy = (float)hi / (float)ho, sx = (float)wi / (float)wo;
+    const int y = min((int)floorf((float)oy * sy), hi - 1);
+    const float* __restrict__ p = in + (size_t)blockIdx.z * hi * wi + (unsigned)(y * wi);
+    f32x4 r;
+    if (wi == wo && vec) {                 // same width: source column == output column, one b128 load
+        r = *(const f32x4*)(p + x);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = p[min((int)floorf((float)min(x + k, wo - 1) * sx), wi - 1)];
+    }
+    store_quad(out + ((size_t)blockIdx.z * ho + oy) * wo, x, wo, vec, r);
 }
 
 static unsigned grid_for(size_t total) {
@@ -164,31 +213,55 @@ static unsigned grid_for(size_t total) {
     return (unsigned)(b < 8192 ? (b ? b : 1) : 8192);
 }
 
+static int row_grid(const char* what, int planes, int ho, int wo, dim3* g) {
+    const long long gx = ((long long)wo + 255) / 256, gy = ((long long)ho + 3) / 4;
+    if (gy > 65535 || planes > 65535) { set_error("%s: more than 262140 rows or 65535 planes per call", what); return -1; }
+    if ((size_t)ho * wo >= 0x7fffffffULL) { set_error("%s: a plane must stay below 2^31 pixels", what); return -1; }
+    *g = dim3((unsigned)gx, (unsigned)gy, (unsigned)planes);
+    return 0;
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
 int launch_resize_bilinear(const float* in, float* out, int planes, int hi, int wi, int ho, int wo, hipStream_t s) {
     if (planes < 1 || hi < 1 || wi < 1 || ho < 1 || wo < 1) { set_error("resize_bilinear: bad shape"); return -1; }
-    const size_t total = (size_t)planes * ho * wo;
-    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, hi, wi, ho, wo, total);
+    if ((size_t)hi * wi >= 0x7fffffffULL) { set_error("resize_bilinear: a plane must stay below 2^31 pixels"); return -1; }
+    dim3 g;
+    if (row_grid("resize_bilinear", planes, ho, wo, &g)) return -1;
+    hipLaunchKernelGGL(resize_bilinear_kernel, g, dim3(64, 4), 0, s, in, out, hi, wi, ho, wo, (int)(wo % 4 == 0 && aligned16(out)));
     return check_launch("resize_bilinear");
 }
 
 int launch_resize_nearest(const float* in, float* out, int planes, int hi, int wi, int ho, int wo, hipStream_t s) {
     if (planes < 1 || hi < 1 || wi < 1 || ho < 1 || wo < 1) { set_error("resize_nearest: bad shape"); return -1; }
-    const size_t total = (size_t)planes * ho * wo;
-    hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, hi, wi, ho, wo, total);
+    if ((size_t)hi * wi >= 0x7fffffffULL) { set_error("resize_nearest: a plane must stay below 2^31 pixels"); return -1; }
+    dim3 g;
+    if (row_grid("resize_nearest", planes, ho, wo, &g)) return -1;
+    hipLaunchKernelGGL(resize_nearest_kernel, g, dim3(64, 4), 0, s, in, out, hi, wi, ho, wo,
+                       (int)(wo % 4 == 0 && aligned16(out) && aligned16(in)));
     return check_launch("resize_nearest");
 }
 
-// out = content * (1 - m) + stylized * m   (test.py:236); mask has 1 or c channels, batch 1 or n
+// out = content * (1 - m) + stylized * m   (test.py:236); mask has 1 or c channels, batch 1 or n.
+// blockIdx.y = plane (img * c + ch): the mask plane is block-uniform; VEC: one b128 per operand per thread.
+template <bool VEC>
 __global__ __launch_bounds__(256) void mask_composite_kernel(const float* __restrict__ content, const float* __restrict__ sty,
                                                              const float* __restrict__ mask, int mask_c, int mask_n,
-                                                             float* __restrict__ out, int c, int hw, size_t total) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int pix = (int)(i % hw);
-        const size_t r = i / hw;
-        const int ch = (int)(r % c);
-        const int img = (int)(r / c);
-        const float m = mask[((size_t)(mask_n == 1 ? 0 : img) * mask_c + (mask_c == 1 ? 0 : ch)) * hw + pix];
-        out[i] = content[i] * (1.0f - m) + sty[i] * m;
+                                                             float* __restrict__ out, int c, int hw) {
+    const unsigned plane = blockIdx.y, img = plane / (unsigned)c, ch = plane - img * (unsigned)c;
+    const size_t base = (size_t)plane * hw;
+    const float* __restrict__ mp = mask + ((size_t)(mask_n == 1 ? 0u : img) * mask_c + (mask_c == 1 ? 0u : ch)) * hw;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1);
+    if (i >= hw) return;
+    if (VEC) {
+        const f32x4 m = *(const f32x4*)(mp + i), a = *(const f32x4*)(content + base + i), b = *(const f32x4*)(sty + base + i);
+        f32x4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = a[k] * (1.0f - m[k]) + b[k] * m[k];
+        *(f32x4*)(out + base + i) = r;
+    } else {
+        const float m = mp[i];
+        out[base + i] = content[base + i] * (1.0f - m) + sty[base + i] * m;
     }
 }
 
@@ -197,29 +270,56 @@ int launch_mask_composite(const float* content, const float* stylized, const flo
     if (n < 1 || c < 1 || hw < 1) { set_error("mask_composite: bad shape"); return -1; }
     if (mask_c != 1 && mask_c != c) { set_error("mask_composite: mask channels %d must be 1 or %d", mask_c, c); return -1; }
     if (mask_n != 1 && mask_n != n) { set_error("mask_composite: mask batch %d must be 1 or %d", mask_n, n); return -1; }
-    const size_t total = (size_t)n * c * hw;
-    hipLaunchKernelGGL(mask_composite_kernel, dim3(grid_for(total)), dim3(256), 0, s, content, stylized, mask, mask_c, mask_n, out, c, hw, total);
+    if ((long long)n * c > 65535) { set_error("mask_composite: more than 65535 planes per call"); return -1; }
+    const bool vec = hw % 4 == 0 && aligned16(content) && aligned16(stylized) && aligned16(mask) && aligned16(out);
+    const unsigned gx = (unsigned)(((size_t)hw / (vec ? 4 : 1) + 255) / 256);
+    if (vec)
+        hipLaunchKernelGGL(mask_composite_kernel<true>, dim3(gx, n * c), dim3(256), 0, s, content, stylized, mask, mask_c, mask_n, out, c, hw);
+    else
+        hipLaunchKernelGGL(mask_composite_kernel<false>, dim3(gx, n * c), dim3(256), 0, s, content, stylized, mask, mask_c, mask_n, out, c, hw);
     return check_launch("mask_composite");
 }
 
 // NCHW float -> NHWC u8, x*255 + 0.5 clamped to [0,255] then truncated (torchvision save_image)
-__global__ __launch_bounds__(256) void quantize_u8_kernel(const float* __restrict__ in, uint8_t* __restrict__ out, int c, int hw,
-                                                          size_t total) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % c);
-        const size_t r = i / c;
-        const int pix = (int)(r % hw);
-        const size_t img = r / hw;
-        float v = in[(img * c + ch) * (size_t)hw + pix] * 255.0f + 0.5f;
-        v = fminf(fmaxf(v, 0.f), 255.f);
-        out[i] = (uint8_t)v;
-    }
+__device__ __forceinline__ unsigned quant1(float x) {
+    float v = x * 255.0f + 0.5f;
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    return (unsigned)v;
+}
+
+// c == 3, hw % 4 == 0: a thread owns 4 pixels = three b128 plane loads -> 12 packed bytes (one 96-bit store); blockIdx.y = image
+__global__ __launch_bounds__(256) void quantize_u8_rgb4_kernel(const float* __restrict__ in, uint8_t* __restrict__ out, int hw) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q * 4 >= hw) return;
+    const float* __restrict__ p = in + (size_t)blockIdx.y * 3 * hw + q * 4;
+    const f32x4 r = *(const f32x4*)p, g = *(const f32x4*)(p + hw), b = *(const f32x4*)(p + 2 * (size_t)hw);
+    unsigned by[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { by[3 * k] = quant1(r[k]); by[3 * k + 1] = quant1(g[k]); by[3 * k + 2] = quant1(b[k]); }
+    using u32x3 = __attribute__((ext_vector_type(3))) unsigned;
+    u32x3 w;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) w[d] = by[4 * d] | (by[4 * d + 1] << 8) | (by[4 * d + 2] << 16) | (by[4 * d + 3] << 24);
+    *(u32x3*)(out + ((size_t)blockIdx.y * hw + q * 4) * 3) = w;
+}
+
+__global__ __launch_bounds__(256) void quantize_u8_kernel(const float* __restrict__ in, uint8_t* __restrict__ out, int c, int hw) {
+    // generic channel count: a thread owns one pixel of image blockIdx.y
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= hw) return;
+    const float* __restrict__ p = in + (size_t)blockIdx.y * c * hw + pix;
+    uint8_t* __restrict__ o = out + ((size_t)blockIdx.y * hw + pix) * c;
+    for (int ch = 0; ch < c; ++ch) o[ch] = (uint8_t)quant1(p[(size_t)ch * hw]);
 }
 
 int launch_quantize_u8(const float* in, uint8_t* out, int n, int c, int h, int w, hipStream_t s) {
     if (n < 1 || c < 1 || h < 1 || w < 1) { set_error("quantize_u8: bad shape"); return -1; }
-    const size_t total = (size_t)n * c * h * w;
-    hipLaunchKernelGGL(quantize_u8_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, c, h * w, total);
+    if ((size_t)h * w * c >= 0x7fffffffULL || n > 65535) { set_error("quantize_u8: image too large (2^31 elements) or batch > 65535"); return -1; }
+    const int hw = h * w;
+    if (c == 3 && hw % 4 == 0 && aligned16(in) && ((uintptr_t)out & 3) == 0)
+        hipLaunchKernelGGL(quantize_u8_rgb4_kernel, dim3((hw / 4 + 255) / 256, n), dim3(256), 0, s, in, out, hw);
+    else
+        hipLaunchKernelGGL(quantize_u8_kernel, dim3((hw + 255) / 256, n), dim3(256), 0, s, in, out, c, hw);
     return check_launch("quantize_u8");
 }
 
@@ -243,36 +343,184 @@ __device__ __forceinline__ int reflect_border(int v, int n) {
 __device__ __forceinline__ int clamp_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 
 #pragma clang fp contract(off)
+struct WarpTap { int o00, o01, o10, o11, w00, w01, w10, w11; };      // pixel offsets into prev (x c) and 2^15-scaled weights
+
+__device__ __forceinline__ WarpTap warp_tap(int x, int y, float fx_, float fy_, int h, int w, int c) {
+    const float mx = (float)x + fx_, my = (float)y + fy_;
+    const int ix = __float2int_rn(mx * 32.0f), iy = __float2int_rn(my * 32.0f);
+    const int sx = clamp_short(ix >> 5), sy = clamp_short(iy >> 5), fx = ix & 31, fy = iy & 31;
+    const int x0 = reflect_border(sx, w), x1 = reflect_border(sx + 1, w);
+    const int y0 = reflect_border(sy, h), y1 = reflect_border(sy + 1, h);
+    WarpTap t;
+    t.w00 = (32 - fx) * (32 - fy) * 32; t.w01 = fx * (32 - fy) * 32; t.w10 = (32 - fx) * fy * 32; t.w11 = fx * fy * 32;
+    t.o00 = (y0 * w + x0) * c; t.o01 = (y0 * w + x1) * c; t.o10 = (y1 * w + x0) * c; t.o11 = (y1 * w + x1) * c;
+    return t;
+}
+
+__device__ __forceinline__ unsigned warp_blend1(const uint8_t* __restrict__ prev, const WarpTap& t, int ch, unsigned cur, float alpha,
+                                                float one_minus_alpha) {
+    const int wv = ((int)prev[t.o00 + ch] * t.w00 + (int)prev[t.o01 + ch] * t.w01 + (int)prev[t.o10 + ch] * t.w10 +
+                    (int)prev[t.o11 + ch] * t.w11 + (1 << 14)) >> 15;          // <= 255 by construction
+    const float a = alpha * ((float)cur / 255.0f);
+    const float bq = one_minus_alpha * ((float)wv / 255.0f);
+    const float b = (a + bq) * 255.0f;
+    return (unsigned)fminf(fmaxf(b, 0.f), 255.f);
+}
+
+// c == 3, h*w % 4 == 0: a thread owns 4 consecutive pixels (flat index): two b128 flow loads, 12 current bytes as three
+// dwords, 12 output bytes as one 96-bit store; the 48 gathered bytes of the previous frame stay byte loads
+__global__ __launch_bounds__(256) void warp_blend_u8_rgb4_kernel(const uint8_t* __restrict__ cur, const uint8_t* __restrict__ prev,
+                                                                 const float* __restrict__ flow, uint8_t* __restrict__ out, int h, int w,
+                                                                 float alpha, float one_minus_alpha) {
+    const int total = h * w;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    const f32x4 fx = *(const f32x4*)(flow + i), fy = *(const f32x4*)(flow + total + i);
+    using u32x3 = __attribute__((ext_vector_type(3))) unsigned;
+    const u32x3 cw = *(const u32x3*)(cur + (size_t)i * 3);
+    int y = i / w, x = i - y * w;
+    unsigned by[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const WarpTap t = warp_tap(x, y, fx[k], fy[k], h, w, 3);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const int b = 3 * k + ch;
+            by[b] = warp_blend1(prev, t, ch, (cw[b >> 2] >> (8 * (b & 3))) & 255u, alpha, one_minus_alpha);
+        }
+        if (++x == w) { x = 0; ++y; }
+    }
+    u32x3 o;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) o[d] = by[4 * d] | (by[4 * d + 1] << 8) | (by[4 * d + 2] << 16) | (by[4 * d + 3] << 24);
+    *(u32x3*)(out + (size_t)i * 3) = o;
+}
+
 __global__ __launch_bounds__(256) void warp_blend_u8_kernel(const uint8_t* __restrict__ cur, const uint8_t* __restrict__ prev,
                                                             const float* __restrict__ flow, uint8_t* __restrict__ out, int h, int w,
                                                             int c, float alpha, float one_minus_alpha) {
     const int total = h * w;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int y = i / w, x = i - y * w;
-        const float mx = (float)x + flow[i], my = (float)y + flow[(size_t)total + i];
-        const int ix = __float2int_rn(mx * 32.0f), iy = __float2int_rn(my * 32.0f);
-        const int sx = clamp_short(ix >> 5), sy = clamp_short(iy >> 5), fx = ix & 31, fy = iy & 31;
-        const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
-        const int x0 = reflect_border(sx, w), x1 = reflect_border(sx + 1, w);
-        const int y0 = reflect_border(sy, h), y1 = reflect_border(sy + 1, h);
-        for (int ch = 0; ch < c; ++ch) {
-            const int p00 = prev[((size_t)y0 * w + x0) * c + ch], p01 = prev[((size_t)y0 * w + x1) * c + ch];
-            const int p10 = prev[((size_t)y1 * w + x0) * c + ch], p11 = prev[((size_t)y1 * w + x1) * c + ch];
-            const int wv = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;          // <= 255 by construction
-            const float a = alpha * ((float)cur[(size_t)i * c + ch] / 255.0f);
-            const float bq = one_minus_alpha * ((float)wv / 255.0f);
-            const float b = (a + bq) * 255.0f;
-            out[(size_t)i * c + ch] = (uint8_t)fminf(fmaxf(b, 0.f), 255.f);
-        }
-    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int y = i / w, x = i - y * w;
+    const WarpTap t = warp_tap(x, y, flow[i], flow[total + i], h, w, c);
+    for (int ch = 0; ch < c; ++ch)
+        out[(size_t)i * c + ch] = (uint8_t)warp_blend1(prev, t, ch, cur[(size_t)i * c + ch], alpha, one_minus_alpha);
 }
 
 int launch_warp_blend_u8(const uint8_t* cur, const uint8_t* prev, const float* flow, uint8_t* out, int h, int w, int c, float alpha,
                          float one_minus_alpha, hipStream_t s) {
     if (h < 1 || w < 1 || c < 1) { set_error("warp_blend_u8: bad shape"); return -1; }
-    hipLaunchKernelGGL(warp_blend_u8_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, s, cur, prev, flow, out, h, w, c, alpha,
-                       one_minus_alpha);
+    if ((size_t)h * w * c >= 0x7fffffffULL) { set_error("warp_blend_u8: frame too large (2^31 bytes)"); return -1; }
+    const int total = h * w;
+    if (c == 3 && total % 4 == 0 && aligned16(flow) && ((uintptr_t)cur & 3) == 0 && ((uintptr_t)out & 3) == 0)
+        hipLaunchKernelGGL(warp_blend_u8_rgb4_kernel, dim3((total / 4 + 255) / 256), dim3(256), 0, s, cur, prev, flow, out, h, w, alpha,
+                           one_minus_alpha);
+    else
+        hipLaunchKernelGGL(warp_blend_u8_kernel, dim3((total + 255) / 256), dim3(256), 0, s, cur, prev, flow, out, h, w, c, alpha,
+                           one_minus_alpha);
     return check_launch("warp_blend_u8");
+}
+
+// ---- cv2.resize(uint8 HWC, dsize, interpolation=cv2.INTER_AREA) of the video post-pass (reference video/utils.py:352-353) ----
+// OpenCV 4.x modules/imgproc/src/resize.cpp, the true-area branch (scale_x >= 1 and scale_y >= 1):
+//   * equal sizes: copy;
+//   * both scales integers ("is_area_fast"): box sum in int, D = saturate_cast<uchar>(sum * (1.f / area)) = round-half-even;
+//     2 x 2 with 1, 3 or 4 channels takes ResizeAreaFastVec's integer form (a + b + c + d + 2) >> 2;
+//   * otherwise resizeArea_<uchar, float>: per axis a tap table (computeResizeAreaTab, double arithmetic: a partial
+//     first cell, whole cells weighted 1 / cellWidth, a partial last cell; partial cells below 1e-3 dropped), the row buffer
+//     accumulates S * alpha over the x taps in table order in float, rows are combined sum = beta * buf, then
+//     sum += beta * buf, and the result is saturate_cast<uchar> (round-half-even).  Evaluated here in exactly that order
+//     without contraction; the tables are recomputed per thread in double (a handful of IEEE divisions).
+// Upscaling (a scale < 1: OpenCV emulates INTER_AREA with its fixed-point bilinear path) is not built: the video caller only
+// ever shrinks or copies (stylised frames are >= the target resolution).  Unpinned against OpenCV itself (cv2 is absent).
+struct AreaTaps { int s0, n; float a_first, a_mid, a_last; };      // taps s0 .. s0 + n - 1; weights: first, middle ones, last
+
+__device__ __forceinline__ AreaTaps area_taps(int d, int ssize, double scale) {
+    const double fsx1 = (double)d * scale, fsx2 = fsx1 + scale;
+    const double cell = fmin(scale, (double)ssize - fsx1);
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    sx2 = min(sx2, ssize - 1);
+    sx1 = min(sx1, sx2);
+    const bool left = (double)sx1 - fsx1 > 1e-3, right = fsx2 - (double)sx2 > 1e-3;
+    AreaTaps t;
+    t.s0 = left ? sx1 - 1 : sx1;
+    t.n = (left ? 1 : 0) + (sx2 - sx1) + (right ? 1 : 0);
+    const float mid = (float)(1.0 / cell);
+    t.a_mid = mid;
+    t.a_first = left ? (float)(((double)sx1 - fsx1) / cell) : mid;
+    t.a_last = right ? (float)(fmin(fmin(fsx2 - (double)sx2, 1.), cell) / cell) : mid;
+    if (t.n == 1 && left && !right) t.a_last = t.a_first;       // a single tap: first == last
+    if (t.n == 1 && right && !left) t.a_first = t.a_last;
+    return t;
+}
+
+__device__ __forceinline__ uint8_t sat_u8_rne(float v) {
+    const int r = __float2int_rn(v);
+    return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+}
+
+// mode 0: general (fractional) scale; 1: integer scale box mean; 2: 2 x 2 fast form
+template <int MODE>
+__global__ __launch_bounds__(256) void resize_area_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int hi, int wi,
+                                                             int c, int ho, int wo, double scale_x, double scale_y, int isx, int isy) {
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= wo || dy >= ho) return;
+    const uint8_t* __restrict__ src = in + (size_t)blockIdx.z * hi * wi * c;
+    uint8_t* __restrict__ dst = out + ((size_t)blockIdx.z * ho * wo + (size_t)dy * wo + dx) * c;
+    if constexpr (MODE == 0) {
+        const AreaTaps tx = area_taps(dx, wi, scale_x), ty = area_taps(dy, hi, scale_y);
+        for (int ch = 0; ch < c; ++ch) {
+            float sum = 0.f;
+            for (int j = 0; j < ty.n; ++j) {
+                const float beta = j == 0 ? ty.a_first : (j == ty.n - 1 ? ty.a_last : ty.a_mid);
+                const uint8_t* __restrict__ S = src + ((size_t)(ty.s0 + j) * wi + tx.s0) * c + ch;
+                float buf = 0.f;
+                for (int k = 0; k < tx.n; ++k) {
+                    const float alpha = k == 0 ? tx.a_first : (k == tx.n - 1 ? tx.a_last : tx.a_mid);
+                    buf = buf + (float)S[(size_t)k * c] * alpha;
+                }
+                sum = j == 0 ? beta * buf : sum + beta * buf;
+            }
+            dst[ch] = sat_u8_rne(sum);
+        }
+    } else {
+        const float scale = 1.f / (float)(isx * isy);
+        for (int ch = 0; ch < c; ++ch) {
+            int sum = 0;
+            for (int sy = 0; sy < isy; ++sy) {
+                const uint8_t* __restrict__ S = src + ((size_t)(dy * isy + sy) * wi + (size_t)dx * isx) * c + ch;
+                for (int sx = 0; sx < isx; ++sx) sum += S[(size_t)sx * c];
+            }
+            dst[ch] = MODE == 2 ? (uint8_t)((sum + 2) >> 2) : sat_u8_rne((float)sum * scale);
+        }
+    }
+}
+
+int launch_resize_area_u8(const uint8_t* in, uint8_t* out, int n, int hi, int wi, int c, int ho, int wo, hipStream_t s) {
+    if (n < 1 || hi < 1 || wi < 1 || c < 1 || ho < 1 || wo < 1) { set_error("resize_area_u8: bad shape"); return -1; }
+    if (ho > hi || wo > wi) {
+        set_error("resize_area_u8: %dx%d -> %dx%d enlarges an axis; only the true-area branch of cv2.INTER_AREA (shrink or copy) is built", hi, wi, ho, wo);
+        return -1;
+    }
+    if ((size_t)hi * wi * c >= 0x7fffffffULL || n > 65535 || (ho + 3) / 4 > 65535) { set_error("resize_area_u8: frame or batch too large"); return -1; }
+    if (ho == hi && wo == wi) {
+        if (hipMemcpyAsync(out, in, (size_t)n * hi * wi * c, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            set_error("resize_area_u8: copy failed: %s", hipGetErrorString(hipGetLastError()));
+            return -2;
+        }
+        return 0;
+    }
+    // cv::resize: inv_scale = dsize / ssize (double), scale = 1. / inv_scale, iscale = saturate_cast<int>(scale) (= cvRound)
+    const double scale_x = 1. / ((double)wo / wi), scale_y = 1. / ((double)ho / hi);
+    const int isx = (int)nearbyint(scale_x), isy = (int)nearbyint(scale_y);
+    const bool fast = fabs(scale_x - isx) < 2.220446049250313e-16 && fabs(scale_y - isy) < 2.220446049250313e-16;
+    const dim3 g((wo + 63) / 64, (ho + 3) / 4, n), b(64, 4);
+    if (!fast) hipLaunchKernelGGL(resize_area_u8_kernel<0>, g, b, 0, s, in, out, hi, wi, c, ho, wo, scale_x, scale_y, 0, 0);
+    else if (isx == 2 && isy == 2 && (c == 1 || c == 3 || c == 4))
+        hipLaunchKernelGGL(resize_area_u8_kernel<2>, g, b, 0, s, in, out, hi, wi, c, ho, wo, scale_x, scale_y, isx, isy);
+    else hipLaunchKernelGGL(resize_area_u8_kernel<1>, g, b, 0, s, in, out, hi, wi, c, ho, wo, scale_x, scale_y, isx, isy);
+    return check_launch("resize_area_u8");
 }
 
 // ---- layout transposes through a 32x33 LDS tile: [n][R][C] -> [n][C][R] ------------------------------------

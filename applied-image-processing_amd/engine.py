@@ -20,6 +20,19 @@ class AdaINEngine:
         self.enc = rt.pack_encoder(vgg_state_dict, self.device)
         self.dec = rt.pack_decoder(decoder_state_dict, self.device)
         self.s_mean = self.s_std = None
+        self._style_cache = {}
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+    def set_style_cached(self, key, style):
+        """``set_style`` once per ``key`` (the job drivers switch between a few styles through a clip, video/utils.py:335-337:
+        each style image is encoded once per rank, its 2 x 512 statistics are kept)."""
+        if key not in self._style_cache:
+            self.set_style(style)
+            self._style_cache[key] = (self.s_mean, self.s_std)
+        self.s_mean, self.s_std = self._style_cache[key]
+        return self
 
     def set_style(self, style):
         """style [1,3,hs,ws] (or [1,4,...]: the alpha channel is dropped as in test.py:60-61)."""
@@ -56,6 +69,7 @@ class AdaINEngine:
 
     def composite(self, content, stylized, masks):
         """masks [n|1, 1|3, hm, wm] float -> content*(1-m) + resize(stylized)*m (test.py:222-236)."""
+        content = content.to(self.device, torch.float32).contiguous()
         size = tuple(content.shape[-2:])
         m = rt.resize_nearest(masks.to(self.device, torch.float32), size)
         s = rt.resize_bilinear(stylized, size)
@@ -63,6 +77,13 @@ class AdaINEngine:
 
     def to_u8(self, images):
         return rt.quantize_u8(images)
+
+    def resize_area_u8(self, frames_u8, dsize):
+        """cv2.resize(frame, dsize, interpolation=cv2.INTER_AREA) per frame (video/utils.py:352-353); dsize = (width, height)."""
+        return rt.resize_area_u8(frames_u8, dsize)
+
+    def temporal_blend(self, frames_u8, flows, alpha=0.7):
+        return temporal_blend(frames_u8, flows, alpha)
 
 
 def precompute_guides(engine, views, names, output_dir, masks=None, content_size=512, crop=False, alpha=0.5,
@@ -142,14 +163,18 @@ class GraphedStylize:
     test.py:160) the per-kernel launch overhead of the eager path is a visible share of a 1-2 ms forward.
     Every C-ABI entry point only enqueues work on the given stream and neither allocates nor synchronises, which is
     what makes the capture legal.  The style must be set before capture (its statistics are baked into the graph's
-    input buffers by reference, so ``engine.set_style`` followed by a new capture is needed to change it)."""
+    input buffers by reference, so ``engine.set_style`` followed by a new capture is needed to change it).  The graph
+    holds raw addresses of the engine's packed weights and style statistics: the object keeps those tensors alive
+    (``_keep``), so a later ``engine.set_style`` cannot hand their memory back to the allocator under a live graph."""
 
     def __init__(self, engine, n, h, w, alpha=0.5, to_u8=False):
         self.engine = engine
+        self._keep = (engine.s_mean, engine.s_std, engine.enc, engine.dec)
         self.static_in = torch.zeros((n, 3, h, w), dtype=torch.float32, device=engine.device)
         side = torch.cuda.Stream(engine.device)
         side.wait_stream(torch.cuda.current_stream(engine.device))
-        with torch.cuda.stream(side):            # warm-up outside the capture: workspaces, lazy library state
+        with torch.cuda.stream(side):            # warm-up outside the capture (lazy library state); the activation workspaces are
+                                                 # keyed by stream, so the capture below allocates its own from the graph's pool
             for _ in range(2):
                 out = engine.stylize(self.static_in, alpha)
                 if to_u8:

@@ -45,6 +45,7 @@ SIGNATURES = {
     "adain_mask_composite": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_quantize_u8": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_warp_blend_u8": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p]),
+    "adain_resize_area_u8": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 6 + [_c_void_p]),
     "adain_nhwc_to_nchw": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_nchw_to_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_conv3x3_packed_floats": (_c_size_t, [_c_int, _c_int]),
@@ -328,6 +329,23 @@ def warp_blend_u8(cur, prev, flow, alpha):
         _check(lib().adain_warp_blend_u8(cur.data_ptr(), prev.data_ptr(), flow.data_ptr(), out.data_ptr(), h, w, c, float(alpha),
                                          float(1 - alpha), _stream()), "adain_warp_blend_u8")
     return out
+
+
+def resize_area_u8(frames, dsize):
+    """cv2.resize(frame, dsize, interpolation=cv2.INTER_AREA) on uint8 HWC frames: [h,w,c] or a batch [n,h,w,c];
+    ``dsize`` = (width, height) as in cv2 (reference video/utils.py:352-353).  Shrinking / same size only."""
+    frames = _dev(frames, "frames", torch.uint8)
+    single = frames.dim() == 3
+    if single:
+        frames = frames.unsqueeze(0)
+    if frames.dim() != 4:
+        raise AdainHipError(f"resize_area_u8: expected [h,w,c] or [n,h,w,c] uint8, got {tuple(frames.shape)}")
+    n, hi, wi, c = frames.shape
+    wo, ho = int(dsize[0]), int(dsize[1])
+    out = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=frames.device)
+    with torch.cuda.device(frames.device):
+        _check(lib().adain_resize_area_u8(frames.data_ptr(), out.data_ptr(), n, hi, wi, c, ho, wo, _stream()), "adain_resize_area_u8")
+    return out[0] if single else out
 
 
 def nhwc_to_nchw(x):

@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the AdaIN hot path on MI355X (BASELINE.json metric: stylised Mpixels/s).
 
-One "step" = one full ``style_transfer_simple`` forward (reference Style_3DGS/AdaIN/test.py:74-81) on
-one synthetic batch that is already resident in HBM: encode content (1024x1024, batch 1) + encode
-style (512x512) + channel statistics + AdaIN/alpha blend + decode.  The style is re-encoded every
-step, as the reference does on every call; nothing is cached across steps.  fp32 throughout.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
+N > 1 is launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1 is launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``:
-one process per GPU, every rank runs the same per-GPU workload on its own frames (weak scaling, no
-data-path collective); the timed region is bracketed by barrier + synchronize and the MAX over ranks is
-reported.  After the timed region the uint8 frames are gathered once to rank 0 over RCCL ("final gather").
+A "step" is one pass of the hot path over one batch of synthetic frames that are resident in HBM when the timed region starts:
+  config 2 (default, BASELINE configs[1])  one full ``style_transfer_simple`` (reference Style_3DGS/AdaIN/test.py:74-81): encode the
+            1024x1024 content, encode the 512x512 style (re-encoded every step, as every reference call does), statistics,
+            AdaIN + alpha blend, decode.
+  config 3  the depth-aware ``style_transfer`` (test.py:52-71) at 2048x2048 with a proximity map.
+  config 4  the video job (video/utils.py:297-369): ``--batch`` 1080p frames per GPU per step through
+            ``jobs.stylize_frames_sharded`` (one style for the clip: its statistics are computed once per rank), uint8 out.
+  config 5  the 3DGS guide-view job (Style_3DGS/train.py:86-115): ``--batch`` masked 1200x1600 views per GPU per step.
+With more than one rank (or under torch.distributed.run) the frame list of a step is cut into contiguous per-rank blocks
+(weak scaling: ``--batch`` frames per GPU) and every step ENDS with the path's one collective: the finished uint8 frames are
+gathered to rank 0 over RCCL (asynchronously for configs 2/3: the gather of step k overlaps the compute of step k+1).  The
+device gather must run over RCCL ("nccl" backend): if the process group cannot provide it, or if there are more ranks than
+GPUs, the benchmark exits non-zero instead of silently degrading (``--rehearse`` allows both for single-GPU rehearsals and
+labels the JSON line).  The timed region is bracketed by barrier + synchronize; the MAX over ranks is reported.
 
-Rank 0 prints ONE JSON line.  ``roofline`` is measured live with HIP events recorded by the C ABI on the
-launch stream around every 3x3-conv launch (the dominant kernel family, fp32 MFMA); ``cpu_baseline`` is
-the CPU oracle (a torch-CPU restatement of the reference path) timed on this node's host cores on the
-same workload.
+Rank 0 prints ONE JSON line.
+  roofline      the dominant kernel family (3x3 convolutions, fp32 MFMA): HIP events recorded by the C ABI on the launch stream
+                around every conv launch.  ``achieved`` = multiplies the kernel EXECUTES on the matrix pipe (the Winograd
+                F(4,3) x F(2,3) form needs 24 per 72 of the direct algorithm's) x 2 flop / time, ``frac`` = achieved / 157.3
+                TFLOP/s (<= 1 by construction); the direct-convolution rate is reported as ``algorithmic_tflops``.
+  secondary     the HBM-bound kernels: algorithmic bytes / event time, against 8 TB/s.
+  cpu_baseline  the CPU oracle (torch-CPU restatement of the reference path) timed on this node's host cores on a bounded
+                sample of the same workload; it also yields the PSNR / relative L2 of the GPU output.
 """
 import argparse
 import json
@@ -32,11 +43,14 @@ import torch
 import torch.distributed as dist
 
 import applied_image_processing_amd.arch as arch
+import applied_image_processing_amd.engine as engine_mod
+import applied_image_processing_amd.jobs as jobs
 import applied_image_processing_amd.runtime as rt
 import applied_image_processing_amd.sharding as sh
 import applied_image_processing_amd.synth as synth
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0           # same guide: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable by a float4 copy)
 WINOGRAD = os.environ.get("ADAIN_WINOGRAD", "1") != "0"      # the C library's default; ADAIN_WINOGRAD=0 = direct implicit GEMM
 WINO_FORM = int(os.environ.get("ADAIN_WINO_MH", "5"))          # the C library's default: 5 = F(4,3) x F(2,3); others F(2x2,3x3)
 # multiplies the conv3x3 kernel executes on the matrix pipe per direct-convolution multiply
@@ -47,9 +61,10 @@ CONV_KERNEL = ("conv3x3_mfma_kernel / conv3x3_persist_kernel" if not WINOGRAD el
 WORKLOADS = {
     2: "configs[1]: {h}x{w} AdaIN forward (style_transfer_simple), batch={b} per GPU, style {hs}x{ws} re-encoded every step, alpha=0.5",
     3: "configs[2]: {h}x{w} depth-aware AdaIN (style_transfer, proximity-map blend), batch={b} per GPU, style {hs}x{ws} re-encoded every step",
-    4: "configs[3]: video frames {h}x{w}, {b} frames per GPU per step, one {hs}x{ws} style (statistics cached for the job), uint8 out",
-    5: "configs[4]: 3DGS guide views {h}x{w} with masks, {b} views per GPU per step, one {hs}x{ws} style, mask composite + uint8 out",
+    4: "configs[3]: video job, frames {h}x{w}, {b} frames per GPU per step, one {hs}x{ws} style (statistics cached per rank), uint8 out",
+    5: "configs[4]: 3DGS guide-view job, views {h}x{w} with masks, {b} views per GPU per step, one {hs}x{ws} style, mask composite + uint8 out",
 }
+SIZES = {2: (1024, 1024), 3: (2048, 2048), 4: (1080, 1920), 5: (1200, 1600)}
 
 
 def enc_conv3x3_flops(n, h, w):
@@ -78,40 +93,88 @@ def make_events(n):
     return evs
 
 
-class Step:
-    """One pass of the hot path on raw device buffers through the C ABI.  ``config``:
-    2: style_transfer_simple, 1024x1024 content + 512x512 style re-encoded every step (test.py:74-81)
-    3: style_transfer (depth-aware), 2048x2048 content + depth map + 512x512 style (test.py:52-71)
-    4: video frames 1080x1920, `batch` frames per step, ONE style for the job (statistics computed once, before the
-       timed region: a video has one style, video/utils.py:341), output quantised to uint8
-    5: 3DGS guide views 1200x1600 with masks, `batch` views per step, one style, mask composite + uint8 (train.py:86-115)
-    """
+class Timer:
+    """HIP-event pairs around host-side calls on the current stream (the stream every kernel of the path is launched on)."""
 
-    def __init__(self, device, config=2, seed_offset=0, size=None, style_size=512, batch=1, alpha=0.5):
-        self.config, self.alpha, self.batch = config, alpha, batch
-        self.h, self.w = {2: (1024, 1024), 3: (2048, 2048), 4: (1080, 1920), 5: (1200, 1600)}[config]
+    def __init__(self, on):
+        self.on, self.spans = on, []
+
+    def __call__(self, name, nbytes, fn, *a, **k):
+        if not self.on:
+            return fn(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        self.spans.append((name, nbytes, e0, e1))
+        return r
+
+
+def synth_frame(config, index, h, w):
+    """Frame ``index`` of the synthetic job of ``config``: f32 [1,3,h,w] in [0,1); config 5 views carry ~30 %
+    exact-zero background pixels (the reference's mask is ``gt_image_np > 0``, train.py:97)."""
+    base = {2: 3, 3: 5, 4: 7, 5: 1000}[config]
+    x = torch.from_numpy(synth.image(base + index, 1, h, w))
+    if config == 5:
+        bg = torch.from_numpy(synth.uniform01(2000 + index, h * w).reshape(1, 1, h, w) < 0.3)
+        x = torch.where(bg, torch.zeros_like(x), x)
+    return x
+
+
+class Step:
+    """One pass of the hot path on device-resident inputs through the C ABI (see the module docstring)."""
+
+    def __init__(self, device, config=2, first_frame=0, size=None, style_size=512, batch=1, alpha=0.5):
+        self.config, self.alpha, self.batch, self.device = config, alpha, batch, device
+        self.h, self.w = SIZES[config]
         if size:
             self.h = self.w = size
         self.hs = self.ws = style_size
-        vgg_sd = synth.to_torch(synth.vgg_state_dict(0, full=False))
-        dec_sd = synth.to_torch(synth.decoder_state_dict(0))
-        self.enc = rt.pack_encoder(vgg_sd, device)
-        self.dec = rt.pack_decoder(dec_sd, device)
-        base = {2: 3, 3: 5, 4: 7, 5: 1000}[config] + 1000 * seed_offset
-        self.content = torch.cat([torch.from_numpy(synth.image(base + i, 1, self.h, self.w)) for i in range(batch)]).to(device)
+        self.first_frame = first_frame
+        self.vgg_sd = synth.to_torch(synth.vgg_state_dict(0, full=False))
+        self.dec_sd = synth.to_torch(synth.decoder_state_dict(0))
+        self.engine = engine_mod.AdaINEngine(self.vgg_sd, self.dec_sd, device)      # packs the weights once
+        self.enc, self.dec = self.engine.enc, self.engine.dec
+        self.content = torch.cat([synth_frame(config, first_frame + i, self.h, self.w) for i in range(batch)]).to(device)
         self.style = torch.from_numpy(synth.image(4, 1, self.hs, self.ws)).to(device)
         self.hc, self.wc = rt.encoded_size(self.h, self.w)
         self.style_each_step = config in (2, 3)
         if config == 3:
-            self.depth = [torch.from_numpy(synth.smooth_depth(6 + i, self.h, self.w)).to(device) for i in range(batch)]
+            self.depth = [torch.from_numpy(synth.smooth_depth(6 + first_frame + i, self.h, self.w)).to(device) for i in range(batch)]
         if config == 5:
-            bg = torch.cat([torch.from_numpy(synth.uniform01(2000 + i, self.h * self.w).reshape(1, 1, self.h, self.w) < 0.3)
-                            for i in range(batch)]).to(device)
-            self.content = torch.where(bg, torch.zeros_like(self.content), self.content)
             self.mask = (self.content > 0).float()
         if not self.style_each_step:
-            sf = rt.encode(self.style, self.enc)
-            self.s_mean, self.s_std = rt.mean_std(sf, True)
+            self.engine.set_style_cached(0, self.style)
+            self.s_mean, self.s_std = self.engine.s_mean, self.engine.s_std
+        self.spans = []
+
+    def job_inputs(self, n_job):
+        """The step's job as the job driver sees it: a frame list of ``n_job`` entries (and masks for config 5) of which only
+        this rank's block exists - it is resident in HBM; touching a foreign frame is an error."""
+        step = self
+
+        class Block:
+            def __init__(self, t):
+                self.t = t
+
+            def __len__(self):
+                return n_job
+
+            def __getitem__(self, k):
+                i = k - step.first_frame
+                if not 0 <= i < step.batch:
+                    raise IndexError(f"frame {k} belongs to another rank")
+                return self.t[i]
+
+        return Block(self.content), (Block(self.mask) if self.config == 5 else None)
+
+    def run_job(self, n_job, gather, require_transport=None):
+        """Configs 4 / 5: one step = the sharded job driver over this step's frame list (stylise the own block, [mask
+        composite,] uint8, one gather to rank 0)."""
+        frames, masks = self.job_inputs(n_job)
+        res, info = jobs.stylize_frames_sharded(self.engine, frames, self.style, alpha=self.alpha, masks=masks, sub_batch=self.batch,
+                                                gather=gather, require_transport=require_transport)
+        return res, info
 
     def flops_per_step(self):
         f = arch.conv_flops_encoder(self.h, self.w) * self.batch + arch.conv_flops_decoder(self.hc, self.wc) * self.batch
@@ -151,86 +214,151 @@ class Step:
             f += enc_conv3x3_flops(1, self.hs, self.ws)
         return f + dec_conv3x3_flops(self.batch, self.hc, self.wc)
 
-    def run(self, timed=False):
+    def run(self, timed=False, to_u8=False):
+        """Returns the float result (and the conv event pairs when ``timed``); ``self.u8`` holds the uint8 frames when the
+        config quantises (4, 5) or ``to_u8`` asks for it."""
         ev = []
         self.edge_ev = []
+        T = Timer(timed)
+        n, hc, wc = self.batch, self.hc, self.wc
+        px = n * self.h * self.w
+        feat_bytes = n * hc * wc * 512 * 4
         ev_c = make_events(11) if timed else None
         cf = rt.encode(self.content, self.enc, ev_c)
         if timed:
             ev += [(ev_c[i + 1], ev_c[i + 2]) for i in range(8)]
-            self.edge_ev.append(("conv_first(content)", ev_c[0], ev_c[1]))
+            self.edge_ev.append(("conv_first_kernel (content: NCHW image -> 64-ch NHWC)", px * (12 + 256), ev_c[0], ev_c[1]))
         if self.style_each_step:
             ev_s = make_events(11) if timed else None
             sf = rt.encode(self.style, self.enc, ev_s)
             s_mean, s_std = rt.mean_std(sf, True)
             if timed:
                 ev += [(ev_s[i + 1], ev_s[i + 2]) for i in range(8)]
-                self.edge_ev.append(("conv_first(style)", ev_s[0], ev_s[1]))
         else:
             s_mean, s_std = self.s_mean, self.s_std
-        c_mean, c_std = rt.mean_std(cf, True)
+        c_mean, c_std = T("mean_std_nhwc_partial + finalize (content relu4_1)", feat_bytes, rt.mean_std, cf, True)
         if self.config == 3:
-            p = torch.cat([rt.strength_map(d, self.hc, self.wc, 0.15, 20) for d in self.depth])
-            g = rt.blend_pmap(cf, True, c_mean, c_std, s_mean, s_std, p)
+            p = torch.cat([T("bicubic_minmax + strength_sum + strength_apply (P map)", self.h * self.w * 4 + hc * wc * 12,
+                             rt.strength_map, d, hc, wc, 0.15, 20) for d in self.depth])
+            g = T("adain_blend_kernel (P-map blend)", 2 * feat_bytes, rt.blend_pmap, cf, True, c_mean, c_std, s_mean, s_std, p)
         else:
-            g = rt.blend_alpha(cf, True, c_mean, c_std, s_mean, s_std, self.alpha)
+            g = T("adain_blend_kernel (alpha blend)", 2 * feat_bytes, rt.blend_alpha, cf, True, c_mean, c_std, s_mean, s_std, self.alpha)
         ev_d = make_events(10) if timed else None
         out = rt.decode(g, self.dec, ev_d)
         if timed:
             ev += [(ev_d[i], ev_d[i + 1]) for i in range(8)]
-            self.edge_ev.append(("conv_last", ev_d[8], ev_d[9]))
+            self.edge_ev.append(("conv_last_kernel (64-ch NHWC -> NCHW image)", px * (256 + 12), ev_d[8], ev_d[9]))
         if self.config == 5:
             size = (self.h, self.w)
-            out = rt.mask_composite(self.content, rt.resize_bilinear(out, size), rt.resize_nearest(self.mask, size))
-        if self.config in (4, 5):
-            self.u8 = rt.quantize_u8(out)
+            rs = T("resize_bilinear_kernel", 2 * px * 12, rt.resize_bilinear, out, size)
+            mk = T("resize_nearest_kernel", 2 * px * 12, rt.resize_nearest, self.mask, size)
+            out = T("mask_composite_kernel", 4 * px * 12, rt.mask_composite, self.content, rs, mk)
+        if self.config in (4, 5) or to_u8:
+            self.u8 = T("quantize_u8_kernel", px * 15, rt.quantize_u8, out)
+        self.spans = T.spans
         return (out, ev) if timed else out
 
 
 def load_pmc_traffic(workload_key):
     """HBM bytes per conv3x3 launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
-    tools/summarize_rocprof.py --traffic); None when no profile of this workload is committed."""
+    tools/summarize_rocprof.py --traffic from two separate --pmc runs of this bench command); (None, None) when no profile
+    of this workload is committed.  A constant taken from a profile of the same command, not a live measurement."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        return d.get(workload_key, {}).get("hbm_bytes_per_conv3x3_launch")
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(workload_key, {})
+        return d.get("hbm_bytes_per_conv3x3_launch"), d.get("source")
     except Exception:
-        return None
+        return None, None
 
 
 def measure_roofline(step, reps):
     flops = step.conv3x3_flops()
     total_ms = 0.0
     per_layer = [0.0] * len(flops)
-    step.run()                       # back to steady state after the gather / host work in between
+    sec = {}
+    step.run()                       # back to steady state after the host work in between
     step.run(timed=True)
     torch.cuda.synchronize()
     for _ in range(reps):
         _, ev = step.run(timed=True)
         torch.cuda.synchronize()
         d = [a.elapsed_time(b) for a, b in ev]
-        step.edge_ms = {name: a.elapsed_time(b) for name, a, b in step.edge_ev}
+        for name, nbytes, a, b in step.edge_ev + step.spans:
+            s = sec.setdefault(name, [nbytes, 0.0, 0])
+            s[1] += a.elapsed_time(b)
+            s[2] += 1
         per_layer = [x + y for x, y in zip(per_layer, d)]
         total_ms += sum(d)
     launches = len(flops) * reps
     avg_ms = total_ms / launches
-    achieved = sum(flops) * reps / (total_ms * 1e-3) / 1e12
+    algorithmic = sum(flops) * reps / (total_ms * 1e-3) / 1e12
+    executed = algorithmic * EXECUTED
     layers = [{"gflop": f / 1e9, "ms": t / reps, "tflops": f / (t / reps * 1e-3) / 1e12} for f, t in zip(flops, per_layer)]
-    return {
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-        "traffic": load_pmc_traffic(f"config{step.config}_batch{step.batch}"),
+    traffic, traffic_src = load_pmc_traffic(f"config{step.config}_batch{step.batch}")
+    roof = {
+        "bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
+        "traffic": traffic, "traffic_source": traffic_src,
         "kernel": CONV_KERNEL + f" ({len(flops)} launches/step)",
-        "avg_launch_ms": round(avg_ms, 4), "flop_per_launch_avg": sum(flops) / len(flops),
-        # `achieved` counts the ALGORITHMIC flops of the direct 3x3 convolution (SURVEY 8(d)).  The Winograd kernels execute
-        # 24/72 (F(4,3) x F(2,3): 24 multiplies per 4 x 2 outputs) or 16/36 (F(2x2,3x3)) of those multiplies on the matrix
-        # pipe, which is how `frac` can exceed 1.
-        "executed_mfma_tflops": round(achieved * EXECUTED, 2),
-        "executed_mfma_frac": round(achieved * EXECUTED / PEAK_FP32_MFMA_TFLOPS, 4),
+        "avg_launch_ms": round(avg_ms, 4),
+        # `achieved` counts the multiplies the kernel executes on the matrix pipe: the direct 3x3 convolution's (SURVEY 8(d))
+        # divided by `multiply_reduction`; `algorithmic_tflops` = direct-convolution flops / time (may exceed the peak)
+        "multiply_reduction": round(1.0 / EXECUTED, 3),
+        "executed_gflop_per_launch_avg": round(sum(flops) * EXECUTED / len(flops) / 1e9, 3),
+        "algorithmic_gflop_per_launch_avg": round(sum(flops) / len(flops) / 1e9, 3),
+        "algorithmic_tflops": round(algorithmic, 2),
         "algorithmic_bytes_per_launch_avg": sum(step.conv3x3_algorithmic_bytes()) / len(flops),
-    }, layers
+    }
+    secondary = []
+    for name, (nbytes, ms, cnt) in sec.items():
+        us = ms / cnt * 1e3
+        gbs = nbytes / (us * 1e-6) / 1e9
+        secondary.append({"kernel": name, "bound": "hbm", "algorithmic_bytes": nbytes, "avg_us": round(us, 2),
+                          "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
+    return roof, layers, secondary
 
 
-def cpu_baseline(h, w, hs, ws, gpu_out):
+def measure_pixel_kernels(device, reps=10):
+    """The frame-sized pixel kernels of the video / guide-view jobs on a batch of 8 1080p frames,
+    each launched over rotating buffer sets of more than 512 MiB in total, so that nothing is served from the 256 MiB
+    Infinity Cache: algorithmic bytes / HIP-event time per launch."""
+    n, h, w, sets = 8, 1080, 1920, 3
+    px = n * h * w
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    f32 = [torch.rand((n, 3, h, w), generator=gen).to(device) for _ in range(sets)]
+    f32b = [x.flip(0) for x in f32]
+    msk = [(x > 0.3).float() for x in f32]
+    u8 = [rt.quantize_u8(x) for x in f32]
+    flow = [(torch.rand((2, h, w), generator=gen) * 6 - 3).to(device) for _ in range(sets)]
+    cases = [
+        ("quantize_u8_kernel", px * 15, lambda i: rt.quantize_u8(f32[i])),
+        ("mask_composite_kernel", px * 48, lambda i: rt.mask_composite(f32[i], f32b[i], msk[i])),
+        ("resize_bilinear_kernel (same size)", px * 24, lambda i: rt.resize_bilinear(f32[i], (h, w))),
+        ("resize_nearest_kernel (same size)", px * 24, lambda i: rt.resize_nearest(msk[i], (h, w))),
+        ("resize_area_u8_kernel (1080p -> 540x960, 2x2)", px * 3 * 5 // 4, lambda i: rt.resize_area_u8(u8[i], (w // 2, h // 2))),
+        ("resize_area_u8_kernel (1080p -> 720x1280, fractional)", px * 3 * 13 // 9, lambda i: rt.resize_area_u8(u8[i], (1280, 720))),
+        ("warp_blend_u8_kernel (one 1080p frame)", h * w * (9 + 8), lambda i: rt.warp_blend_u8(u8[i][0], u8[i][1], flow[i], 0.7)),
+    ]
+    out = []
+    for name, nbytes, fn in cases:
+        for i in range(sets):
+            fn(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for r in range(reps):
+            fn(r % sets)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        gbs = nbytes / (us * 1e-6) / 1e9
+        out.append({"kernel": name, "bound": "hbm", "algorithmic_bytes": nbytes, "avg_us": round(us, 2), "achieved": round(gbs, 1),
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "batch": "8 x 1080x1920"})
+    return out
+
+
+def cpu_baseline(step, gpu_out):
+    """The oracle on this node's host cores, same workload, bounded sample (about 10-30 s): configs 2 / 3 whole forwards of
+    the step's first frame; configs 4 / 5 two frames of the job (per-frame cost is constant)."""
     from oracle import adain_oracle as O
 
     # threads actually used: the GPU box grants a 1-GPU job a CPU share of 16 cores (more threads than that
@@ -238,30 +366,54 @@ def cpu_baseline(h, w, hs, ws, gpu_out):
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = int(os.environ.get("ADAIN_CPU_THREADS", min(avail, 16)))
     torch.set_num_threads(cores)
-    vgg_sd = synth.to_torch(synth.vgg_state_dict(0, full=False))
-    dec_sd = synth.to_torch(synth.decoder_state_dict(0))
-    c = torch.from_numpy(synth.image(3, 1, h, w))
-    s = torch.from_numpy(synth.image(4, 1, hs, ws))
+    cfg, h, w = step.config, step.h, step.w
+    vgg_sd, dec_sd = step.vgg_sd, step.dec_sd
+    s = step.style.cpu()
+    frames = [step.content[i:i + 1].cpu() for i in range(min(step.batch, 2))]
+    if cfg in (4, 5) and len(frames) < 2:
+        frames.append(synth_frame(cfg, step.first_frame + 1, h, w))
+
+    def forward(i):
+        c = frames[i]
+        if cfg == 3:
+            return O.style_transfer(vgg_sd, dec_sd, c, s, step.depth[i].cpu(), 1.0, 0.15, 20)
+        out = O.style_transfer_simple(vgg_sd, dec_sd, c, s, step.alpha)
+        if cfg == 5:
+            out = O.mask_composite(c, out, (c[0] > 0))
+        return O.quantize_u8(out) if cfg in (4, 5) else out
+
     times = []
     with torch.no_grad():
-        ref = O.style_transfer_simple(vgg_sd, dec_sd, c, s, 0.5)          # warm-up, also the PSNR reference
+        ref = forward(0)                       # warm-up, also the PSNR reference for frame 0
         t_end = time.time() + 20.0
+        k = 0
         while len(times) < 2 or (time.time() < t_end and len(times) < 5):
             t0 = time.perf_counter()
-            O.style_transfer_simple(vgg_sd, dec_sd, c, s, 0.5)
+            forward(k % len(frames))
             times.append(time.perf_counter() - t0)
+            k += 1
     best = min(times)
-    out = gpu_out[:1].cpu()
-    rel = float((out - ref).norm() / ref.norm())
-    psnr = float(O.psnr(out.clamp(0, 1), ref.clamp(0, 1)).min())
+    if cfg in (4, 5):
+        got = gpu_out[0].cpu()                 # uint8 HWC
+        diff = (got.int() - ref[0].int()).abs()
+        rel = float(diff.float().norm() / ref[0].float().norm())
+        mse = float((diff.float() / 255.0).pow(2).mean())
+        psnr = float("inf") if mse == 0 else 10 * torch.log10(torch.tensor(1.0 / mse)).item()
+    else:
+        got = gpu_out[:1].cpu()
+        rel = float((got - ref).norm() / ref.norm())
+        psnr = float(O.psnr(got.clamp(0, 1), ref.clamp(0, 1)).min())
     try:
         model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
+    what = {2: "full style_transfer_simple forwards", 3: "full depth-aware style_transfer forwards",
+            4: "video-job frames (forward + uint8), per-frame rate", 5: "guide views (forward + mask composite + uint8), per-view rate"}[cfg]
     return {
         "value": round(h * w / 1e6 / best, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-        "sample": f"{len(times)} full forwards of the same workload ({h}x{w} content + {hs}x{ws} style), best of "
-                  f"{len(times)}; median {statistics.median(times):.2f} s; torch {torch.__version__} CPU, {model}",
+        "sample": f"{len(times)} {what} of the same workload ({h}x{w} content, {step.hs}x{step.ws} style"
+                  f"{' encoded once' if cfg in (4, 5) else ''}), best of {len(times)}; median {statistics.median(times):.2f} s; "
+                  f"torch {torch.__version__} CPU, {model}",
     }, psnr, rel
 
 
@@ -275,8 +427,11 @@ def main():
     ap.add_argument("--style-size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 1080p pixel-kernel bandwidth table")
     ap.add_argument("--pcie", action="store_true", help="also report the rate with the frame crossing PCIe both ways (never `value`)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="single-GPU rehearsal of the multi-rank path: ranks may share a GPU and the gather may run over gloo (labelled in the JSON)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -288,19 +443,30 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the AdaIN path has no CPU fallback)")
-    local_rank %= torch.cuda.device_count()           # one rank per GPU on a node; wraps only in single-GPU rehearsals
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local_world > ndev and not args.rehearse:
+        raise SystemExit(f"bench.py: {local_world} ranks on this node but only {ndev} GPU(s) visible: one process per GPU is the "
+                         "contract (RCCL rejects two ranks on one device); use --rehearse for a single-GPU rehearsal")
+    shared_gpu = local_world > ndev
+    torch.cuda.set_device(local_rank % ndev)
+    device = torch.device("cuda", local_rank % ndev)
     use_dist = world > 1 or "RANK" in os.environ      # torch.distributed.run sets RANK even for one process
+    transport = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # gloo carries the host-side rendezvous (barriers, the MAX of the step time); RCCL ("nccl") carries device
-        # tensors, i.e. the final gather of the finished frames over xGMI
-        dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        # tensors, i.e. the gather of the finished frames over xGMI.  With ranks sharing a GPU (--rehearse) RCCL cannot
+        # start, so the rehearsal gathers host copies over gloo: chosen here, up front, identically on every rank.
+        dist.init_process_group("gloo" if shared_gpu else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        transport = "gloo" if shared_gpu else sh.device_transport(torch.empty(0, dtype=torch.uint8, device=device))
+        if transport != "rccl" and not args.rehearse:
+            raise SystemExit(f"bench.py: the device gather would run over {transport!r}, not RCCL: refusing to report a multi-GPU number")
 
-    step = Step(device, config=args.config, seed_offset=rank, size=args.size, style_size=args.style_size, batch=args.batch)
+    step = Step(device, config=args.config, first_frame=rank * args.batch, size=args.size, style_size=args.style_size, batch=args.batch)
     h, w, hs, ws = step.h, step.w, step.hs, step.ws
+    n_job = world * args.batch                        # frames of one step's job over all ranks
 
     def barrier():
         torch.cuda.synchronize()                      # this rank's GPU work is done ...
@@ -308,41 +474,69 @@ def main():
             dist.all_reduce(torch.zeros(1))           # ... and so is everybody else's (host rendezvous, gloo)
         torch.cuda.synchronize()
 
+    pending = []
+    gathered = [None]
+    job_mode = args.config in (4, 5)
+    job_info = {}
+
+    def one_step():
+        if job_mode:          # the job driver: shard -> stylise -> [composite] -> uint8 -> gather (synchronous per job)
+            via_rccl = use_dist and transport == "rccl"
+            res, info = step.run_job(n_job, gather=via_rccl, require_transport="rccl" if via_rccl and world > 1 else None)
+            job_info.update(info)
+            if use_dist and not via_rccl:             # rehearsal: host copies over gloo
+                step.u8 = res
+                gathered[0] = sh.gather_frames(res.cpu(), n_job, dst=0)
+            else:
+                gathered[0] = res
+                if rank == 0 or not use_dist:
+                    step.u8 = res[:args.batch]
+            return None
+        out = step.run(to_u8=use_dist)
+        if use_dist:                                  # the path's one collective: finished uint8 frames -> rank 0
+            u8 = step.u8 if transport == "rccl" else step.u8.cpu()
+            pending.append(sh.gather_frames(u8, n_job, dst=0, async_op=True))
+            if len(pending) > 2:                      # at most two gathers in flight: step k's overlaps step k+1's compute
+                gathered[0] = pending.pop(0)()
+        return out
+
+    def drain():
+        while pending:
+            gathered[0] = pending.pop(0)()
+
     for _ in range(args.warmup):
-        out = step.run()
+        out = one_step()
+    drain()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step.run()
+        out = one_step()
+    drain()
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+        if rank == 0:
+            assert gathered[0] is not None and gathered[0].shape[0] == n_job
 
-    # final gather of the finished uint8 frames to rank 0 (outside the timed region)
-    gather_ms, gather_via = None, None
-    u8 = rt.quantize_u8(out)
+    # one isolated gather (nothing else in flight) for the transport's own cost
+    gather_ms = None
     if use_dist:
+        if job_mode and rank != 0:
+            step.run(to_u8=True)                      # ranks other than 0 hold no local block after a gathered job
+        u8 = step.u8 if transport == "rccl" else step.u8.cpu()
+        barrier()
+        g0 = time.perf_counter()
+        sh.gather_frames(u8, n_job, dst=0)
         torch.cuda.synchronize()
-        for via in ("rccl", "gloo"):
-            try:
-                g0 = time.perf_counter()
-                allf = sh.gather_frames(u8 if via == "rccl" else u8.cpu(), world * args.batch, dst=0)
-                torch.cuda.synchronize()
-                gather_ms, gather_via = (time.perf_counter() - g0) * 1e3, via
-                break
-            except Exception as e:       # the harness must still report the compute numbers if RCCL cannot start
-                print(f"[bench] final gather over {via} failed on rank {rank}: {e}", file=sys.stderr)
-        if rank == 0 and gather_via:
-            assert allf.shape[0] == world * args.batch
+        gather_ms = (time.perf_counter() - g0) * 1e3
 
-    result = None
     if rank == 0:
         ms = dt / args.steps * 1e3
-        value = world * args.batch * h * w / 1e6 / (dt / args.steps)
-        roof, layers = measure_roofline(step, 5)
+        value = n_job * h * w / 1e6 / (dt / args.steps)
+        roof, layers, secondary = measure_roofline(step, 5)
         result = {
             "metric": "stylized Mpixels/sec, AdaIN forward (encode content + encode style + AdaIN + decode)",
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -350,17 +544,24 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.config].format(h=h, w=w, hs=hs, ws=ws, b=args.batch)
                                    + ", fp32, seeded synthetic weights (reference architecture)",
-                       "parallelism": f"frame sharding x{world}, no data-path collective"},
+                       "parallelism": f"frame sharding x{world}: contiguous frame blocks per rank, replicated weights and style "
+                                      "statistics, one gather of the uint8 frames to rank 0 per step" if use_dist else
+                                      "single GPU, no collective"},
             "roofline": roof,
+            "secondary": secondary,
         }
         result["step_tflops"] = round(step.flops_per_step() / (dt / args.steps) / 1e12 * world, 2)
-        if gather_ms is not None:
-            result["final_gather_ms"] = round(gather_ms, 3)
-            result["final_gather_transport"] = gather_via
+        if use_dist:
+            result["gather"] = {"in_timed_step": True, "transport": transport, "isolated_ms": round(gather_ms, 3),
+                                "bytes_per_rank": int(step.u8.numel()), "overlapped_with_next_step": not job_mode}
+            if job_mode:
+                result["gather"]["last_job_gather_ms"] = round(job_info.get("gather_s", 0.0) * 1e3, 3)
+            if args.rehearse:
+                result["rehearsal"] = {"ranks_share_a_gpu": shared_gpu, "note": "not a multi-GPU measurement"}
         if args.pcie:
             # host buffers at the boundary: pinned fp32 frame in, pinned uint8 frame out, copies on the same stream
             host_in = step.content.cpu().pin_memory()
-            host_out = torch.empty((args.batch, out.shape[2], out.shape[3], 3), dtype=torch.uint8).pin_memory()
+            host_out = torch.empty((args.batch, 8 * step.hc, 8 * step.wc, 3), dtype=torch.uint8).pin_memory()
             torch.cuda.synchronize()
             p0 = time.perf_counter()
             for _ in range(args.steps):
@@ -371,16 +572,20 @@ def main():
             pdt = (time.perf_counter() - p0) / args.steps
             result["pcie_inclusive"] = {"value": round(args.batch * h * w / 1e6 / pdt, 3), "unit": "Mpixels/s",
                                         "ms_per_step": round(pdt * 1e3, 4), "what": "pinned fp32 frame H2D + forward + uint8 D2H per step"}
-        if world == 1 and not args.no_cpu and args.config == 2 and args.batch == 1:
-            cb, psnr, rel = cpu_baseline(h, w, hs, ws, out)
+        if world == 1 and not args.no_secondary:
+            result["secondary"] += measure_pixel_kernels(device)
+        if job_mode:
+            result["job_driver"] = "jobs.stylize_frames_sharded"
+        if world == 1 and not args.no_cpu:
+            out = step.run()
+            torch.cuda.synchronize()
+            cb, psnr, rel = cpu_baseline(step, step.u8 if args.config in (4, 5) else out)
             result["cpu_baseline"] = cb
-            result["psnr_db_vs_cpu"] = round(psnr, 2)
+            result["psnr_db_vs_cpu"] = round(psnr, 2) if psnr != float("inf") else "inf"
             result["rel_l2_vs_cpu"] = float(f"{rel:.3e}")
         if args.layers and layers:
             for i, L in enumerate(layers):
                 print(f"layer {i:2d}: {L['gflop']:8.2f} GF  {L['ms']:8.4f} ms  {L['tflops']:7.2f} TF/s", file=sys.stderr)
-            for name, ms in getattr(step, "edge_ms", {}).items():
-                print(f"{name}: {ms:.4f} ms", file=sys.stderr)
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.all_reduce(torch.zeros(1))

@@ -115,6 +115,14 @@ int adain_quantize_u8(const float* image_nchw, uint8_t* out_nhwc, int n, int c, 
 int adain_warp_blend_u8(const uint8_t* cur_u8, const uint8_t* prev_u8, const float* flow, uint8_t* out_u8, int h, int w,
                         int c, float alpha, float one_minus_alpha, adain_stream_t stream);
 
+/* cv2.resize(frames_u8, (wo, ho), interpolation=cv2.INTER_AREA) of the same post-pass (reference video/utils.py:352-353) on
+ * n HWC uint8 frames [n][hi][wi][c] -> [n][ho][wo][c].  The true-area branch of OpenCV's resize (both axes shrink or keep
+ * their size): equal sizes copy; integer scales box-average in int with round-half-even ((a+b+c+d+2)>>2 for 2x2); other
+ * scales use resizeArea_'s float tap tables in OpenCV's accumulation order.  Enlarging an axis returns ADAIN_EINVAL (OpenCV
+ * switches to its bilinear emulation there; the video caller never enlarges). */
+int adain_resize_area_u8(const uint8_t* in_u8, uint8_t* out_u8, int n, int hi, int wi, int c, int ho, int wo,
+                         adain_stream_t stream);
+
 /* ---- layout changes at the boundary ([n][c][hw] <-> [n][hw][c]) ------------------------------------------ */
 int adain_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, adain_stream_t stream);
 int adain_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, adain_stream_t stream);

@@ -1,14 +1,19 @@
-"""world_size-2 gloo test of the multi-GPU driver logic on CPU: frame-block sharding, replicated style
-statistics, the single gather at the end, and the barrier + max-over-ranks timing of bench.py."""
+"""world_size-2 gloo tests of the multi-GPU job drivers on CPU: frame-block sharding, per-rank style statistics, frame-local
+post work before the gather, the single gather to rank 0, the rank-0 recurrence, and the barrier + max-over-ranks timing of
+bench.py.  The real driver functions of ``applied-image-processing_amd/jobs.py`` run here; only the engine (the object whose
+methods launch the HIP kernels) is replaced by a CPU stand-in built on the oracle."""
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import applied_image_processing_amd.jobs as jobs
 import applied_image_processing_amd.sharding as sh
+from oracle import adain_oracle as O
 
 
 def _free_port():
@@ -19,43 +24,158 @@ def _free_port():
     return p
 
 
-def _fake_stylize(frames):
-    # stands in for the per-frame GPU forward: deterministic, frame-local
-    return (frames.float() * 3 + 1).to(torch.uint8)
+class StubEngine:
+    """CPU stand-in with AdaINEngine's method surface.  'Stylise' = a frame-local affine map that depends on the current
+    style, so a wrong style schedule, a wrong shard or a wrong frame order all change the result."""
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self._cache, self.cur, self.encoded = {}, None, 0
+
+    def synchronize(self):
+        pass
+
+    def set_style(self, style):
+        self.encoded += 1
+        self.cur = float(style.mean())
+        return self
+
+    def set_style_cached(self, key, style):
+        if key not in self._cache:
+            self.set_style(style)
+            self._cache[key] = self.cur
+        self.cur = self._cache[key]
+        return self
+
+    def stylize(self, content, alpha=0.5, pmap=None):
+        return content * alpha + self.cur * (1 - alpha)
+
+    def stylize_depth(self, content, depth_maps, offset=0.15, prominence=20):
+        p = torch.stack([d.mean() for d in depth_maps]).view(-1, 1, 1, 1)
+        return content * p + self.cur * offset
+
+    def composite(self, content, stylized, masks):
+        return O.mask_composite(content, stylized, masks[0]) if masks.shape[0] == 1 else torch.cat(
+            [O.mask_composite(content[i:i + 1], stylized[i:i + 1], masks[i]) for i in range(masks.shape[0])])
+
+    def to_u8(self, images):
+        return O.quantize_u8(images)
+
+    def resize_area_u8(self, frames_u8, dsize):
+        return torch.from_numpy(np.stack([O.resize_area_u8(f.numpy(), dsize) for f in frames_u8]))
+
+    def temporal_blend(self, frames_u8, flows, alpha=0.7):
+        return torch.from_numpy(O.temporal_blend(frames_u8.numpy(), flows.numpy(), alpha))
 
 
-def _worker(rank, world, port, n_frames, q):
+def _inputs(n, h=12, w=20):
+    g = torch.Generator().manual_seed(5)
+    frames = [torch.rand(3, h, w, generator=g) for _ in range(n)]
+    styles = [torch.full((1, 3, 4, 4), 0.2), torch.full((1, 3, 4, 4), 0.9), torch.full((1, 3, 4, 4), 0.5)]
+    flows = (torch.rand(max(n - 1, 0), 2, 6, 10, generator=g) - 0.5) * 3
+    masks = [(torch.rand(3, h, w, generator=g) > 0.3) for _ in range(n)]
+    return frames, styles, flows, masks
+
+
+def _video_worker(rank, world, port, n, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        lo, hi = sh.shard_range(n_frames, world, rank)
-        frames = torch.arange(n_frames * 6, dtype=torch.float32).view(n_frames, 1, 2, 3) % 50
-        local = _fake_stylize(frames[lo:hi])
-        out = sh.gather_frames(local, n_frames, dst=0)
+        frames, styles, flows, _ = _inputs(n)
+
+        class Lazy:                       # proves a rank only touches its own block
+            touched = []
+
+            def __len__(self):
+                return n
+
+            def __getitem__(self, k):
+                Lazy.touched.append(k)
+                return frames[k]
+
+        eng = StubEngine()
+        out, info = jobs.video_style_transfer_sharded(eng, Lazy(), styles, flows=flows, target_resolution=(10, 6), blend_alpha=0.7,
+                                                      sub_batch=2)
+        lo, hi = sh.shard_range(n, world, rank)
+        assert sorted(set(Lazy.touched)) == list(range(lo, hi)) and info["shard"] == (lo, hi)
+        assert info["transport"] == "gloo"
         # bench.py timing contract: barrier on both sides, MAX over ranks
         t = torch.tensor([0.5 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if rank == 0:
-            q.put((out.clone(), float(t)))
+            q.put((out.clone(), float(t), eng.encoded))
         else:
             assert out is None
-        dist.barrier()
+        jobs.host_barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames", [7, 8, 1])
-def test_shard_and_gather_world2(n_frames):
+def _run(target, world, args):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    out, tmax = q.get()
+    res = q.get()
     for p in procs:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
-    frames = torch.arange(n_frames * 6, dtype=torch.float32).view(n_frames, 1, 2, 3) % 50
-    assert torch.equal(out, _fake_stylize(frames))
+    return res
+
+
+@pytest.mark.parametrize("n_frames", [7, 8, 1])
+def test_video_job_world2_equals_single_process(n_frames):
+    out, tmax, _ = _run(_video_worker, 2, (n_frames,))
+    frames, styles, flows, _ = _inputs(n_frames)
+    ref, _ = jobs.video_style_transfer_sharded(StubEngine(), frames, styles, flows=flows, target_resolution=(10, 6), blend_alpha=0.7)
+    assert out.shape == (n_frames, 6, 10, 3) and out.dtype == torch.uint8
+    assert torch.equal(out, ref)
     assert tmax == 1.5
+
+
+def _guides_worker(rank, world, port, n, outdir, write, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames, styles, _, masks = _inputs(n)
+        names = [f"view_{i:03d}" for i in range(n)]
+        paths, info = jobs.precompute_guides_sharded(StubEngine(), frames, names, outdir, styles[1], masks=masks, content_size=0,
+                                                     save_ext=".png", write=write, sub_batch=3)
+        assert all(p.exists() for p in paths.values())        # every file exists on every rank's return
+        if rank == 0:
+            q.put(sorted(str(p) for p in paths.values()))
+        jobs.host_barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("write", ["dst", "local"])
+def test_guides_job_world2_files(tmp_path, write):
+    from PIL import Image
+
+    n = 5
+    files = _run(_guides_worker, 2, (n, str(tmp_path / write), write))
+    frames, styles, _, masks = _inputs(n)
+    eng = StubEngine().set_style(styles[1])
+    assert [os.path.basename(f) for f in files] == [f"view_{i:03d}.png" for i in range(n)]   # reference naming (train.py:104-114)
+    for i, f in enumerate(files):
+        c = frames[i][None]
+        want = O.quantize_u8(O.mask_composite(c, eng.stylize(c, 0.5), masks[i]))[0].numpy()
+        assert np.array_equal(np.asarray(Image.open(f)), want)
+
+
+def test_style_schedule_matches_reference_loop():
+    # video/utils.py:311-337: frames_per_style = max(1, n // ns); switch at i > 0 and i % frames_per_style == 0, capped
+    assert jobs.style_schedule(7, 3) == [0, 0, 1, 1, 2, 2, 2]
+    assert jobs.style_schedule(3, 5) == [0, 1, 2]
+    assert jobs.style_schedule(4, 1) == [0, 0, 0, 0]
+    with pytest.raises(ValueError):
+        jobs.style_schedule(4, 0)
+
+
+def test_shard_ranges():
+    assert sh.shard_counts(300, 8) == [38, 38, 38, 38, 37, 37, 37, 37]
+    assert sh.shard_counts(512, 8) == [64] * 8
+    assert [sh.shard_range(3, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 3)]

@@ -102,3 +102,22 @@ def test_synth_is_deterministic_and_conditioned(weights):
     with torch.no_grad():
         f = O.encode(vgg, T(synth.image(11, 1, 64, 64)))
     assert 0.3 < float(f.std()) < 10.0 and 0.1 < float(f.mean()) < 10.0
+
+
+def test_resize_area_known_answers():
+    """cv2.INTER_AREA restatement (parity unpinned against OpenCV: no cv2 here): construction-level known answers."""
+    a = np.arange(24, dtype=np.uint8).reshape(4, 6)
+    assert O.resize_area_u8(a, (6, 4)) is not a and np.array_equal(O.resize_area_u8(a, (6, 4)), a)        # same size: copy
+    assert O.resize_area_u8(a, (3, 2)).tolist() == [[4, 6, 8], [16, 18, 20]]         # 2x2: (0+1+6+7+2)>>2 = 4 (3.5 rounds UP)
+    # integer 3x2 box: sums 0+1+2+6+7+8 = 24 -> 24 * (1/6 as float) = 4.0000001 -> 4; second column 3+4+5+9+10+11 = 42 -> 7
+    assert O.resize_area_u8(a, (2, 2)).tolist() == [[4, 7], [16, 19]]
+    # round-half-even of the box mean: [1, 2] -> 1.5 -> 2, [2, 3] -> 2.5 -> 2 (the 2x2 fast form would give 3)
+    b = np.array([[1, 2, 2, 3]], dtype=np.uint8)
+    assert O.resize_area_u8(b, (2, 1)).tolist() == [[2, 2]]
+    # fractional scale 1.5: taps (1, 0.5) -> weights 2/3, 1/3; a constant image stays constant, a ramp stays monotone
+    c = np.full((9, 9, 3), 200, dtype=np.uint8)
+    assert (O.resize_area_u8(c, (6, 6)) == 200).all()
+    ramp = np.tile(np.arange(0, 90, 10, dtype=np.uint8), (3, 1))
+    r = O.resize_area_u8(ramp, (6, 3))
+    # dx 0: (0*1 + 10*.5)/1.5 = 3.33 -> 3; dx 1: (10*.5 + 20*1)/1.5 = 16.67 -> 17; dx 2: (30*1 + 40*.5)/1.5 = 33.3 -> 33 ...
+    assert r[0].tolist() == [3, 17, 33, 47, 63, 77] and (r == r[0]).all()
