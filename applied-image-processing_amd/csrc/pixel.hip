@@ -167,6 +167,10 @@ __device__ __forceinline__ void store_quad(float* __restrict__ row, int x, int w
     }
 }
 
+// SAMEW: wi == wo, so the x scale is exactly 1, rx == ox, x0 == ox and lx1 == 0: the four outputs of a thread read the b128 at
+// their own columns plus one more element (the x1 taps still enter the sum with weight 0, as in ATen, so a NaN / Inf neighbour
+// propagates identically).
+template <bool SAMEW>
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int hi,
                                                               int wi, int ho, int wo, int vec) {
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4, oy = blockIdx.y * 4 + threadIdx.y;
@@ -178,15 +182,28 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     const float* __restrict__ p0 = in + (size_t)blockIdx.z * hi * wi + (unsigned)(y0 * wi);
     const float* __restrict__ p1 = in + (size_t)blockIdx.z * hi * wi + (unsigned)(y1 * wi);
     f32x4 r;
+    if (SAMEW) {
+        const f32x4 a0 = *(const f32x4*)(p0 + x), a1 = *(const f32x4*)(p1 + x);
+        const int xe = min(x + 4, wi - 1);
+        const float e0 = p0[xe], e1 = p1[xe];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int ox = min(x + k, wo - 1);
-        const float rx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.f);
-        const int x0 = min((int)rx, wi - 1), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
-        const float lx1 = fminf(fmaxf(rx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
-        const float top = lx0 * p0[x0] + lx1 * p0[x1];
-        const float bot = lx0 * p1[x0] + lx1 * p1[x1];
-        r[k] = ly0 * top + ly1 * bot;
+        for (int k = 0; k < 4; ++k) {
+            const float n0 = k < 3 ? a0[k < 3 ? k + 1 : 3] : e0, n1 = k < 3 ? a1[k < 3 ? k + 1 : 3] : e1;
+            const float top = 1.f * a0[k] + 0.f * n0;
+            const float bot = 1.f * a1[k] + 0.f * n1;
+            r[k] = ly0 * top + ly1 * bot;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ox = min(x + k, wo - 1);
+            const float rx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.f);
+            const int x0 = min((int)rx, wi - 1), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+            const float lx1 = fminf(fmaxf(rx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
+            const float top = lx0 * p0[x0] + lx1 * p0[x1];
+            const float bot = lx0 * p1[x0] + lx1 * p1[x1];
+            r[k] = ly0 * top + ly1 * bot;
+        }
     }
     store_quad(out + ((size_t)blockIdx.z * ho + oy) * wo, x, wo, vec, r);
 }
@@ -228,7 +245,9 @@ int launch_resize_bilinear(const float* in, float* out, int planes, int hi, int 
     if ((size_t)hi * wi >= 0x7fffffffULL) { set_error("resize_bilinear: a plane must stay below 2^31 pixels"); return -1; }
     dim3 g;
     if (row_grid("resize_bilinear", planes, ho, wo, &g)) return -1;
-    hipLaunchKernelGGL(resize_bilinear_kernel, g, dim3(64, 4), 0, s, in, out, hi, wi, ho, wo, (int)(wo % 4 == 0 && aligned16(out)));
+    const int vec = (int)(wo % 4 == 0 && aligned16(out));
+    if (wi == wo && vec && aligned16(in)) hipLaunchKernelGGL(resize_bilinear_kernel<true>, g, dim3(64, 4), 0, s, in, out, hi, wi, ho, wo, vec);
+    else hipLaunchKernelGGL(resize_bilinear_kernel<false>, g, dim3(64, 4), 0, s, in, out, hi, wi, ho, wo, vec);
     return check_launch("resize_bilinear");
 }
 
@@ -329,6 +348,9 @@ int launch_quantize_u8(const float* in, uint8_t* out, int n, int c, int h, int w
 // (fedcba|abcdefgh|hgfedcb), in cv2.remap's own uint8 fixed-point arithmetic (below).  cv2 is not installed in the build
 // image, so the fixed-point restatement is checked against the oracle only (parity unpinned against OpenCV itself).
 __device__ __forceinline__ int reflect_border(int v, int n) {
+    if ((unsigned)v < (unsigned)n) return v;                      // inside the frame: almost every tap
+    const int once = v < 0 ? -1 - v : 2 * n - 1 - v;              // one reflection covers displacements up to a frame size
+    if ((unsigned)once < (unsigned)n) return once;
     const int p = 2 * n;      // BORDER_REFLECT has period 2n: ...cba|abc...xyz|zyx...
     v %= p;
     if (v < 0) v += p;

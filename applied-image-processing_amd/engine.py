@@ -20,18 +20,18 @@ class AdaINEngine:
         self.enc = rt.pack_encoder(vgg_state_dict, self.device)
         self.dec = rt.pack_decoder(decoder_state_dict, self.device)
         self.s_mean = self.s_std = None
-        self._style_cache = {}
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)
 
-    def set_style_cached(self, key, style):
-        """``set_style`` once per ``key`` (the job drivers switch between a few styles through a clip, video/utils.py:335-337:
-        each style image is encoded once per rank, its 2 x 512 statistics are kept)."""
-        if key not in self._style_cache:
-            self.set_style(style)
-            self._style_cache[key] = (self.s_mean, self.s_std)
-        self.s_mean, self.s_std = self._style_cache[key]
+    def style_stats(self):
+        """The current style's channel statistics (mean, std), each [1,512] on the GPU: what ``set_style`` computed."""
+        return self.s_mean, self.s_std
+
+    def use_style_stats(self, stats):
+        """Switches to statistics obtained earlier from ``style_stats`` (the job drivers move between a few styles through a
+        clip, video/utils.py:335-337: each style image is encoded once, its 2 x 512 statistics are kept by the job)."""
+        self.s_mean, self.s_std = stats
         return self
 
     def set_style(self, style):

@@ -58,13 +58,14 @@ def host_barrier(group=None):
 
 def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, depth_maps=None, depth_offset=0.15,
                            depth_prominence=20, masks=None, post=None, sub_batch=4, group=None, dst=0, gather=True,
-                           require_transport=None):
+                           require_transport=None, style_cache=None):
     """Stylises ``frames`` (a sequence of [3,h,w] float tensors in [0,1], all one size, indexed lazily: a rank only ever
     touches its own block) and returns ``(frames_u8, info)``: the uint8 frames [n,H,W,3] in frame order on rank ``dst``
     (None on the other ranks, the local block when ``gather=False``) and a dict with the shard, timings and the transport.
 
     styles          one style tensor [1|.,3,hs,ws] or a list of them; ``style_of[i]`` picks the style of frame i
-                    (``style_schedule``); the statistics of each style are computed once per rank and kept.
+                    (``style_schedule``); every style image is encoded once per rank and call, its 2 x 512 statistics
+                    are kept for the call (pass a dict as ``style_cache`` to keep them across calls with the SAME styles).
     depth_maps      optional sequence of [h0,w0] proximity maps, one per frame -> depth-aware blend (test.py:52-71) with
                     ``depth_offset`` / ``depth_prominence``; otherwise the ``alpha`` blend (test.py:74-81).
     masks           optional sequence of [1|3,hm,wm] masks -> content-mask composite (test.py:222-236).
@@ -90,14 +91,17 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
     t0 = time.perf_counter()
     blocks = []
     cur_style = None
+    stats = style_cache if style_cache is not None else {}
     i = lo
     while i < hi:
         j = i + 1
         while j < hi and j - i < sub_batch and style_of[j] == style_of[i]:
             j += 1
         if style_of[i] != cur_style:
-            engine.set_style_cached(style_of[i], style_list[style_of[i]])
             cur_style = style_of[i]
+            if cur_style not in stats:
+                stats[cur_style] = engine.set_style(style_list[cur_style]).style_stats()
+            engine.use_style_stats(stats[cur_style])
         content = torch.stack([frames[k][:3] for k in range(i, j)]).to(dev, torch.float32)
         if depth_maps is not None:
             out = engine.stylize_depth(content, [depth_maps[k].to(dev, torch.float32) for k in range(i, j)], depth_offset,

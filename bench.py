@@ -144,8 +144,8 @@ class Step:
         if config == 5:
             self.mask = (self.content > 0).float()
         if not self.style_each_step:
-            self.engine.set_style_cached(0, self.style)
-            self.s_mean, self.s_std = self.engine.s_mean, self.engine.s_std
+            self.s_mean, self.s_std = self.engine.set_style(self.style).style_stats()
+            self.style_cache = {0: (self.s_mean, self.s_std)}      # one style for the whole job: encoded once per rank
         self.spans = []
 
     def job_inputs(self, n_job):
@@ -173,7 +173,7 @@ class Step:
         composite,] uint8, one gather to rank 0)."""
         frames, masks = self.job_inputs(n_job)
         res, info = jobs.stylize_frames_sharded(self.engine, frames, self.style, alpha=self.alpha, masks=masks, sub_batch=self.batch,
-                                                gather=gather, require_transport=require_transport)
+                                                gather=gather, require_transport=require_transport, style_cache=self.style_cache)
         return res, info
 
     def flops_per_step(self):

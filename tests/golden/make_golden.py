@@ -28,6 +28,17 @@ def T(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
+def localized_inputs():
+    """Foreground / background uint8 images of case E as run_localized_style_transfer builds them (:228-229): two complementary
+    regions of one frame, everything outside a region exactly black; the regions differ in size and in colour statistics."""
+    h, w = 40, 56
+    a = (synth.image(51, 1, h, w)[0].transpose(1, 2, 0) * np.float32(255)).astype(np.uint8)
+    b = (synth.image(52, 1, h, w)[0].transpose(1, 2, 0) * np.float32([200, 120, 90]) + np.float32([30, 60, 20])).astype(np.uint8)
+    yy, xx = np.mgrid[:h, :w]
+    m = (((yy - 18) ** 2 + (xx - 25) ** 2) < 150).astype(np.uint8)         # a disc: ~470 foreground pixels
+    return np.maximum(a, 1) * m[..., None], np.maximum(b, 1) * (1 - m)[..., None]
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -101,6 +112,20 @@ def main():
     src = T(synth.image(41, 1, 24, 31)[0])
     tgt = T(synth.image(42, 1, 20, 27)[0] * 0.5 + 0.25)
     np.savez_compressed(os.path.join(OUT, "case_d.npz"), coral=fn.coral(src, tgt).numpy(), meta=np.array([41, 24, 31, 42, 20, 27]))
+
+    # ---- case E: the localized pipeline's host-side colour transfer (Style_3DGS/localized_style_transfer.py:22-168) ----------
+    loc = ref_loader.load_localized()
+    fg, bg = localized_inputs()
+    lab = loc.rgb_to_lab_pixels(fg.reshape(-1, 3))
+    proj_f, pca_f = loc.apply_pca(loc.rgb_to_lab_pixels(fg[fg.sum(-1) > 0]))
+    proj_b, _ = loc.apply_pca(loc.rgb_to_lab_pixels(bg[bg.sum(-1) > 0]))
+    np.savez_compressed(
+        os.path.join(OUT, "case_e.npz"),
+        lab=lab, rgb_back=loc.lab_to_rgb_pixels(lab), lab_image=loc.rgb_to_lab_image(fg), rgb_image=loc.lab_to_rgb_image(loc.rgb_to_lab_image(fg)),
+        proj_f=proj_f, comp_f=pca_f.components_, mean_f=pca_f.mean_, matched=loc.match_cdf(proj_f, proj_b),
+        matched_rev=loc.match_cdf(proj_b, proj_f), adjusted=loc.color_transfer_foreground(fg, bg),
+        adjusted_swapped=loc.color_transfer_foreground(bg, fg), meta=np.array([51, 52, 40, 56]),
+    )
 
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -30,7 +30,7 @@ class StubEngine:
     device = torch.device("cpu")
 
     def __init__(self):
-        self._cache, self.cur, self.encoded = {}, None, 0
+        self.cur, self.encoded = None, 0
 
     def synchronize(self):
         pass
@@ -40,11 +40,11 @@ class StubEngine:
         self.cur = float(style.mean())
         return self
 
-    def set_style_cached(self, key, style):
-        if key not in self._cache:
-            self.set_style(style)
-            self._cache[key] = self.cur
-        self.cur = self._cache[key]
+    def style_stats(self):
+        return self.cur
+
+    def use_style_stats(self, stats):
+        self.cur = stats
         return self
 
     def stylize(self, content, alpha=0.5, pmap=None):
@@ -102,6 +102,7 @@ def _video_worker(rank, world, port, n, q):
         # bench.py timing contract: barrier on both sides, MAX over ranks
         t = torch.tensor([0.5 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert eng.encoded == len({jobs.style_schedule(n, len(styles))[k] for k in range(lo, hi)})   # one encode per style per rank
         if rank == 0:
             q.put((out.clone(), float(t), eng.encoded))
         else:

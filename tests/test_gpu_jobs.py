@@ -237,3 +237,36 @@ def test_winograd_large_dc_zero_sum_filters(rt, cin, cout, hw):
     errs["torch_cpu_fp32"] = float((cpu32 - ref).abs().max())
     print(f"large-DC cin={cin}: max abs error vs fp64 (|ref| max {float(ref.abs().max()):.2f}): {errs}")
     assert errs[5] <= 2e-4 + 2e-4 * float(ref.abs().max())
+
+
+def test_localized_pipeline_end_to_end(rt, weights, tmp_path):
+    """run_localized_style_transfer (reference Style_3DGS/localized_style_transfer.py:191-245) through the HIP path: the mask
+    provider hook replaces DeepLabV3, the background is stylised with alpha = 1 under the mask, the foreground keeps its
+    pixels up to the colour transfer."""
+    from PIL import Image
+
+    from applied_image_processing_amd import localized as L
+
+    torch.save(synth.to_torch(synth.vgg_state_dict(0, full=True)), tmp_path / "vgg.pth")
+    torch.save(weights[1], tmp_path / "dec.pth")
+    Image.fromarray(u8img(430, 64, 96)).save(tmp_path / "c.png")
+    Image.fromarray(u8img(431, 64, 64)).save(tmp_path / "s.png")
+    yy, xx = np.mgrid[:64, :96]
+    bgmask = (((yy - 30) ** 2 + (xx - 50) ** 2) > 300).astype(np.uint8)[None]          # [1,H,W], 1 = background
+    calls = []
+    L.set_mask_provider(lambda img: (calls.append(img.size), bgmask)[1])
+    try:
+        p = L.run_localized_style_transfer(str(tmp_path / "c.png"), str(tmp_path / "s.png"), output_path=str(tmp_path / "o"),
+                                           file_name="loc", vgg_str=str(tmp_path / "vgg.pth"), decoder_str=str(tmp_path / "dec.pth"),
+                                           content_size=0, save_ext=".png")
+    finally:
+        L.set_mask_provider(None)
+    assert calls == [(96, 64)] and p == f"{tmp_path / 'o'}/localized_style_transfer_result.jpg"
+    sty = np.asarray(Image.open(tmp_path / "o" / "loc.png"))
+    content = np.asarray(Image.open(tmp_path / "c.png"))
+    assert np.array_equal(sty[bgmask[0] == 0], content[bgmask[0] == 0])                # adain_inference kept the foreground
+    want = L.combine_localized(content, sty, bgmask[0])
+    got = np.asarray(Image.open(p))
+    assert got.shape == want.shape and float(np.abs(got.astype(float) - want.astype(float)).mean()) < 8.0    # JPEG of `want`
+    with pytest.raises(RuntimeError, match="provider"):
+        L.run_localized_style_transfer(str(tmp_path / "c.png"), str(tmp_path / "s.png"), output_path=str(tmp_path / "o"))

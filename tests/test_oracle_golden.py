@@ -121,3 +121,40 @@ def test_resize_area_known_answers():
     r = O.resize_area_u8(ramp, (6, 3))
     # dx 0: (0*1 + 10*.5)/1.5 = 3.33 -> 3; dx 1: (10*.5 + 20*1)/1.5 = 16.67 -> 17; dx 2: (30*1 + 40*.5)/1.5 = 33.3 -> 33 ...
     assert r[0].tolist() == [3, 17, 33, 47, 63, 77] and (r == r[0]).all()
+
+
+def test_case_e_localized_colour_transfer_host_path():
+    """The localized pipeline's Reinhard l-alpha-beta / PCA / CDF colour transfer (Style_3DGS/localized_style_transfer.py:22-168)
+    is host-side numpy in the reference and here; pinned to the reference's own outputs (make_golden.py case E, produced with
+    the reference's scikit-learn PCA).  float64 intermediates agree to ~1e-12; the uint8 results come from a TRUNCATING cast,
+    so a last-bit difference of the float64 value may move a channel by one level on isolated pixels."""
+    from applied_image_processing_amd import localized as L
+    from golden.make_golden import localized_inputs
+
+    g = golden("case_e.npz")
+    fg, bg = localized_inputs()
+    lab = L.rgb_to_lab_pixels(fg.reshape(-1, 3))
+    close(lab, g["lab"], 1e-12, 1e-12)
+    assert np.array_equal(L.lab_to_rgb_pixels(g["lab"]), g["rgb_back"])
+    close(L.rgb_to_lab_image(fg), g["lab_image"], 1e-12, 1e-12)
+    assert np.array_equal(L.lab_to_rgb_image(g["lab_image"]), g["rgb_image"])
+    proj_f, pca_f = L.apply_pca(L.rgb_to_lab_pixels(fg[fg.sum(-1) > 0]))
+    proj_b, _ = L.apply_pca(L.rgb_to_lab_pixels(bg[bg.sum(-1) > 0]))
+    close(pca_f.components_, g["comp_f"], 1e-9, 1e-12)          # same axis AND same sign as scikit-learn's
+    close(pca_f.mean_, g["mean_f"], 1e-12, 1e-12)
+    close(proj_f, g["proj_f"], 1e-9, 1e-10)
+    close(L.match_cdf(g["proj_f"], proj_b), g["matched"], 1e-9, 1e-10)
+    close(L.match_cdf(proj_b, g["proj_f"]), g["matched_rev"], 1e-9, 1e-10)
+    for got, want in ((L.color_transfer_foreground(fg, bg), g["adjusted"]), (L.color_transfer_foreground(bg, fg), g["adjusted_swapped"])):
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert got.dtype == np.uint8 and d.max() <= 1 and (d > 0).mean() < 1e-3
+    # black pixels are outside a region and stay untouched; an empty region returns a copy
+    adj = L.color_transfer_foreground(fg, bg)
+    assert (adj[fg.sum(-1) == 0] == 0).all()
+    z = np.zeros_like(fg)
+    assert np.array_equal(L.color_transfer_foreground(z, bg), z) and np.array_equal(L.color_transfer_foreground(fg, z), fg)
+    # the composite of run_localized_style_transfer (:218-236) on arrays
+    m = (fg.sum(-1) == 0).astype(np.uint8)                     # background mask: 1 where the foreground is black
+    content = np.maximum(fg, bg)
+    comb = L.combine_localized(content, bg, m)
+    assert comb.dtype == np.uint8 and np.array_equal(comb[m == 1], bg[m == 1])
