@@ -76,6 +76,15 @@ class HipVGG(_HipSequential):
         feat = rt.encode(x, self.packed(x.device))       # NHWC [N,hc,wc,512]
         return feat.permute(0, 3, 1, 2)                   # [N,512,hc,wc], channels_last in memory
 
+    def forward_many(self, *xs):
+        """``[self(x) for x in xs]`` for image batches of different sizes (content and style of one call, test.py:57,63) in one
+        pass over the layers: bit-identical results, one launch per layer instead of one per layer and batch."""
+        for x in xs:
+            if x.dim() != 4 or x.shape[1] != 3:
+                raise ValueError(f"expected an image batch [N,3,H,W], got {tuple(x.shape)}")
+        xs = [x.float().contiguous() for x in xs]
+        return [f.permute(0, 3, 1, 2) for f in rt.encode_multi(xs, self.packed(xs[0].device))]
+
 
 class HipDecoder(_HipSequential):
     _keys = tuple(rt.DEC_KEYS)

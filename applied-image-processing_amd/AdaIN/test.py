@@ -140,8 +140,7 @@ def style_transfer(vgg, decoder, content, style, depth_map, alpha=1.0, offset=0.
     exactly as in the reference; a 4-channel style loses its alpha channel."""
     assert 0.0 <= alpha <= 1.0
     assert 0.0 <= offset <= 1.0
-    f_content = vgg(content)
-    f_style = vgg(style[:, :3, :, :] if style.shape[1] == 4 else style)
+    f_content, f_style = _encode_both(vgg, content, style[:, :3, :, :] if style.shape[1] == 4 else style)
     strength = compute_stylization_strength_map(depth_map, tuple(f_content.shape[2:]), offset, prominence)
     return decoder(_adain_blend(f_content, f_style, pmap=strength))
 
@@ -149,7 +148,16 @@ def style_transfer(vgg, decoder, content, style, depth_map, alpha=1.0, offset=0.
 def style_transfer_simple(vgg, decoder, content, style, alpha=0.5):
     """``decoder(AdaIN * alpha + content_f * (1 - alpha))`` (reference test.py:74-81)."""
     assert 0.0 <= alpha <= 1.0
-    return decoder(_adain_blend(vgg(content), vgg(style), alpha=alpha))
+    content_f, style_f = _encode_both(vgg, content, style)
+    return decoder(_adain_blend(content_f, style_f, alpha=alpha))
+
+
+def _encode_both(vgg, content, style):
+    """``vgg(content), vgg(style)`` (test.py:57,63 / :76-77).  The package's encoder takes both in one pass over its layers
+    (``HipVGG.forward_many``: same results bit for bit, one launch per layer); any other module is simply called twice."""
+    if isinstance(vgg, net.HipVGG) and content.device == style.device and content.shape[1] == 3 and style.shape[1] == 3:
+        return vgg.forward_many(content, style)
+    return vgg(content), vgg(style)
 
 
 def _adain_blend(content_f, style_f, alpha=None, pmap=None):

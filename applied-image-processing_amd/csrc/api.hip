@@ -190,40 +190,79 @@ size_t adain_encode_workspace_bytes(int n, int h, int w) {
     return (enc_buf_a(n, h, w) + enc_buf_b(n, h, w)) * sizeof(float);
 }
 
-int adain_encode(const float* image, float* feat, const float* packed, void* workspace, size_t ws_bytes, int n, int h,
-                 int w, void* const* ev, adain_stream_t stream) {
-    if (!image || !feat || !packed || !workspace) { set_error("encode: null pointer"); return ADAIN_EINVAL; }
-    if (n < 1 || h < 9 || w < 9) {
-        // relu4_1 must be at least 2x2 for the reflection pad in front of conv4_1 (torch raises there too)
-        set_error("encode: image %dx%d too small (needs h, w >= 9)", h, w);
-        return ADAIN_EINVAL;
+size_t adain_encode_multi_workspace_bytes(int count, const int* n, const int* h, const int* w) {
+    if (count < 1 || count > MAX_CONV_SEGS || !n || !h || !w) return 0;
+    size_t total = 0;
+    for (int i = 0; i < count; ++i) total += adain_encode_workspace_bytes(n[i], h[i], w[i]);
+    return total;
+}
+
+int adain_encode_multi(int count, const float* const* images, float* const* feats, const int* n, const int* h, const int* w,
+                       const float* packed, void* workspace, size_t ws_bytes, void* const* ev, adain_stream_t stream) {
+    if (count < 1 || count > MAX_CONV_SEGS) { set_error("encode: 1..%d image batches per call, got %d", MAX_CONV_SEGS, count); return ADAIN_EINVAL; }
+    if (!images || !feats || !n || !h || !w || !packed || !workspace) { set_error("encode: null pointer"); return ADAIN_EINVAL; }
+    for (int i = 0; i < count; ++i) {
+        if (!images[i] || !feats[i]) { set_error("encode: null pointer"); return ADAIN_EINVAL; }
+        if (n[i] < 1 || h[i] < 9 || w[i] < 9) {
+            // relu4_1 must be at least 2x2 for the reflection pad in front of conv4_1 (torch raises there too)
+            set_error("encode: image %dx%d too small (needs h, w >= 9)", h[i], w[i]);
+            return ADAIN_EINVAL;
+        }
     }
-    if (ws_bytes < adain_encode_workspace_bytes(n, h, w)) { set_error("encode: workspace too small"); return ADAIN_EINVAL; }
+    if (ws_bytes < adain_encode_multi_workspace_bytes(count, n, h, w)) { set_error("encode: workspace too small"); return ADAIN_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     const Offsets f = enc_offsets();
-    float* bufA = (float*)workspace;
-    float* bufB = bufA + enc_buf_a(n, h, w);
+    float* bufA[MAX_CONV_SEGS];
+    float* bufB[MAX_CONV_SEGS];
+    const float* cur[MAX_CONV_SEGS];
+    int ch[MAX_CONV_SEGS], cw[MAX_CONV_SEGS];
+    float* base = (float*)workspace;
     record(ev, 0, s);
-    RET_IF(launch_conv_first(image, bufA, packed, packed + f.first_b, n, h, w, s));
+    for (int i = 0; i < count; ++i) {
+        bufA[i] = base;
+        bufB[i] = base + enc_buf_a(n[i], h[i], w[i]);
+        base = bufB[i] + enc_buf_b(n[i], h[i], w[i]);
+        RET_IF(launch_conv_first(images[i], bufA[i], packed, packed + f.first_b, n[i], h[i], w[i], s));
+        cur[i] = bufA[i];
+        ch[i] = h[i]; cw[i] = w[i];
+    }
     record(ev, 1, s);
-    const float* cur = bufA;
-    int ch = h, cw = w;
-    for (int i = 0; i < 8; ++i) {
+    const bool wino4 = use_winograd() && wino_mh() == 5;
+    for (int l = 0; l < 8; ++l) {
         ConvArgs a{};
-        a.in = cur;
-        a.out = (i == 7) ? feat : (cur == bufA ? bufB : bufA);
-        a.n = n;
-        a.Hs = ch; a.Ws = cw;
-        a.H = ch; a.W = cw;
-        a.cin = ENC[i].cin; a.cout = ENC[i].cout;
+        a.cin = ENC[l].cin; a.cout = ENC[l].cout;
         a.relu = 1;
-        a.pool_out = ENC[i].pool;
-        RET_IF(launch_layer(a, packed, f, i, ENC[i].src, s));
-        record(ev, i + 2, s);
-        cur = a.out;
-        if (ENC[i].pool) { ch = (ch + 1) / 2; cw = (cw + 1) / 2; }
+        a.pool_out = ENC[l].pool;
+        ConvSeg segs[MAX_CONV_SEGS];
+        for (int i = 0; i < count; ++i) {
+            float* out = (l == 7) ? feats[i] : (cur[i] == bufA[i] ? bufB[i] : bufA[i]);
+            segs[i] = ConvSeg{cur[i], out, n[i], ch[i], cw[i], ch[i], cw[i], 0, 0, 0};
+        }
+        if (wino4) {
+            // one launch for every batch: the persistent kernel's tile list runs over all of them (csrc/conv_wino4.hip, SEGMENTS)
+            a.bias = packed + f.b[l];
+            a.wpk = packed + f.w4[l];
+            RET_IF(launch_conv3x3_wino4_multi(a, segs, count, ENC[l].src, s));
+        } else {
+            for (int i = 0; i < count; ++i) {
+                a.in = segs[i].in; a.out = segs[i].out; a.n = n[i];
+                a.Hs = a.H = ch[i]; a.Ws = a.W = cw[i];
+                RET_IF(launch_layer(a, packed, f, l, ENC[l].src, s));
+            }
+        }
+        record(ev, l + 2, s);
+        for (int i = 0; i < count; ++i) {
+            cur[i] = segs[i].out;
+            if (ENC[l].pool) { ch[i] = (ch[i] + 1) / 2; cw[i] = (cw[i] + 1) / 2; }
+        }
     }
     return 0;
+}
+
+int adain_encode(const float* image, float* feat, const float* packed, void* workspace, size_t ws_bytes, int n, int h,
+                 int w, void* const* ev, adain_stream_t stream) {
+    if (!image || !feat) { set_error("encode: null pointer"); return ADAIN_EINVAL; }
+    return adain_encode_multi(1, &image, &feat, &n, &h, &w, packed, workspace, ws_bytes, ev, stream);
 }
 
 size_t adain_decode_workspace_bytes(int n, int hc, int wc) {

@@ -30,6 +30,21 @@ struct ConvArgs {
     unsigned long long* dbg;   // diagnostic builds only (clock stamps); nullptr in production
 };
 
+// One (source, output) tensor pair of a multi-segment launch of the persistent F(4,3) x F(2,3) kernel: the segments of one
+// launch share the layer (weights, bias, cin, cout, source mode, ReLU, output pool) and differ in size and addresses.
+struct ConvSeg {
+    const float* in;    // NHWC source  [n][Hs][Ws][cin]
+    float* out;         // NHWC output  [n][H][W][cout]   (pooled size when the layer's pool_out is set)
+    int n, H, W, Hs, Ws;
+    int tiles_x, tiles_y;
+    int item0;          // first item (tile x channel tile) of this segment in the launch's list
+};
+constexpr int MAX_CONV_SEGS = 4;
+struct ConvSegs {
+    int count, pad_;
+    ConvSeg s[MAX_CONV_SEGS];
+};
+
 // thread-local error text for adain_last_error()
 void set_error(const char* fmt, ...);
 
@@ -58,6 +73,9 @@ inline int device_cu_count() {
 // conv_wino4.hip: F(4,3) x F(2,3) form (its own packed-weight layout, 24 floats per weight pair)
 int launch_pack_wino4(const float* w_oihw, float* packed, int cin, int cout, hipStream_t s);
 int launch_conv3x3_wino4(const ConvArgs& a, int src_mode, hipStream_t s);
+// the same layer over `count` tensor pairs (sizes / addresses from segs[i]: in, out, n, H, W, Hs, Ws; the rest from `layer`):
+// one persistent launch whose tile list covers every segment when there is enough work, one launch per segment otherwise
+int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int count, int src_mode, hipStream_t s);
 // conv_wino3.hip
 int launch_conv3x3_wino3(const ConvArgs& a, int src_mode, hipStream_t s);
 int launch_conv_first(const float* img_nchw, float* out_nhwc, const float* packed, const float* bias, int n, int H,

@@ -93,8 +93,13 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
 // HBM round trip (tools/wino4_phase_probe.py: 3.4-4.1 us of prologue per one-tile workgroup; with cin = 64 both workgroups of a
 // CU are inside their main loops only 22 % of the time).  The wave priority alternates per tile between the two halves of the
 // grid (the SIMD arbiter prefers the older wave; see conv_wino3.hip).
+// SEGMENTS (persistent form only): the tile list may run over up to four (source, output) tensor pairs of different sizes
+// that share the layer's weights - the content batch and the style image of one encoder pass (reference test.py:57,63 encodes
+// both through the same vgg) - so that the deep style-branch layers, too small to fill the chip on their own, ride in the
+// content launch's list.  A tile's geometry (H, W, pointers) comes from its segment's descriptor, re-read from the kernel
+// arguments at the two places that need it (the next tile's halo offsets, the epilogue's stores).
 template <int MODE, int DIAG = 0, bool PERSIST = false>
-__global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(ConvArgs a, int items, int prio_mode) {
+__global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(ConvArgs a, ConvSegs m, int items, int prio_mode) {
     __shared__ __attribute__((aligned(16))) float smem[DIAG == 2 ? W4_PEX + 8192 : (DIAG == 1 ? W4_PEX + 1024 : W4_PEX)];
     float* const Rs = smem;
     unsigned* const steplog = (unsigned*)(smem + W4_PEX);     // DIAG 1, 2: [wave][96] low words of s_memtime
@@ -114,16 +119,28 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     };
 
     // block -> (channel tile fastest, pixel tile, image) inside a contiguous per-XCD range (halo reuse in L2)
-    const int tiles = a.tiles_x * a.tiles_y;
+    int tiles = a.tiles_x * a.tiles_y;
     const int nct = a.cout / 32;
     int lid = blockIdx.x, ct, pt, img;
+    // geometry of the tile being computed (gH, gW: conv output size; gWs: source row length) and of its tensors
+    int gH = a.H, gW = a.W, gWs = a.Ws, gtx = a.tiles_x;
+    int seg = 0;                                     // persistent form: segment of the current tile
+    auto seg_of = [&](int it) {
+        int si = 0;
+        for (int k = 1; k < m.count; ++k)
+            if (it >= m.s[k].item0) si = k;
+        return si;
+    };
     // persistent form: the tile list of this workgroup = items lo + slot, lo + slot + stride, ... below hi
     const int stride = gridDim.x >> 3;
     const int lo = (int)((long long)items * (blockIdx.x & 7) / 8), hi = (int)((long long)items * ((blockIdx.x & 7) + 1) / 8);
     int item = lo + (blockIdx.x >> 3);
     if constexpr (PERSIST) {
         if (item >= hi) return;
-        lid = item;
+        seg = seg_of(item);
+        lid = item - m.s[seg].item0;
+        gH = m.s[seg].H; gW = m.s[seg].W; gWs = m.s[seg].Ws; gtx = m.s[seg].tiles_x;
+        tiles = gtx * m.s[seg].tiles_y;
     } else if (a.xcd_order && (gridDim.x & 7) == 0) {
         lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
     }
@@ -136,30 +153,32 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         pt = lid % tiles;
         img = lid / tiles;
     }
-    int tx0 = (pt % a.tiles_x) * 32, ty0 = (pt / a.tiles_x) * 8;
+    int tx0 = (pt % gtx) * 32, ty0 = (pt / gtx) * 8;
     const int nst = a.cin / W4_KR;
     const int nch = a.cin / 8;
 
-    const unsigned src_bytes = (unsigned)a.Hs * a.Ws * a.cin * 4u;
-    const size_t src_img = (size_t)a.Hs * a.Ws * a.cin;
-    rsrc_t src = make_rsrc(a.in + img * src_img, src_bytes);
+    auto src_of = [&](const float* base, int Hs, int Ws, int im) {
+        const size_t per = (size_t)Hs * Ws * a.cin;
+        return make_rsrc(base + im * per, (unsigned)(per * 4u));
+    };
+    rsrc_t src = PERSIST ? src_of(m.s[seg].in, m.s[seg].Hs, m.s[seg].Ws, img) : src_of(a.in, a.Hs, a.Ws, img);
     const rsrc_t wsr = make_rsrc(a.wpk, (unsigned)a.cin * a.cout * 96u);
 
     // ---- raw halo staging: 340 pixels x 4 quads over 256 threads x 6 items ---------------------------------------------------
     int roff[W4_RITEMS];
-    auto halo_offsets = [&](int x0, int y0) {
+    auto halo_offsets = [&](int x0, int y0, int H, int W, int Ws) {
         const int t = PERSIST ? (lane_now() | (wj << 6)) : tid;        // persistent: recomputed per tile, nothing hoisted
 #pragma unroll
         for (int k = 0; k < W4_RITEMS; ++k) {
             const int idx = t + k * 256;
             const int hp = min(idx >> 2, W4_HALO - 1), q = idx & 3;
             const int hy = hp / W4_HALO_W, hx = hp - hy * W4_HALO_W;
-            int y = reflect1(y0 + hy - 1, a.H), x = reflect1(x0 + hx - 1, a.W);
+            int y = reflect1(y0 + hy - 1, H), x = reflect1(x0 + hx - 1, W);
             if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
-            roff[k] = ((y * a.Ws + x) * a.cin + q * 4) * 4;
+            roff[k] = ((y * Ws + x) * a.cin + q * 4) * 4;
         }
     };
-    halo_offsets(tx0, ty0);
+    halo_offsets(tx0, ty0, gH, gW, gWs);
     f32x4 rawreg[W4_RITEMS];
     auto raw_load = [&](int soff) {
 #pragma unroll
@@ -219,11 +238,13 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         const int tl = wj * 8 + tt;
         const float* Pr = smem + tl * 32 + ((q8 ^ ((tl >> 1) & 7)) << 2);
         const f32x4 bias4 = *(const f32x4*)(a.bias + ct * 32 + 4 * q8);
-        const int Ho = a.pool_out ? (a.H + 1) >> 1 : a.H, Wo = a.pool_out ? (a.W + 1) >> 1 : a.W;
-        const rsrc_t dst = make_rsrc(a.out + (size_t)img * Ho * Wo * a.cout, (unsigned)(Ho * Wo * a.cout) * 4u);
+        const int eH = PERSIST ? m.s[seg].H : a.H, eW = PERSIST ? m.s[seg].W : a.W;
+        float* const eout = PERSIST ? m.s[seg].out : a.out;
+        const int Ho = a.pool_out ? (eH + 1) >> 1 : eH, Wo = a.pool_out ? (eW + 1) >> 1 : eW;
+        const rsrc_t dst = make_rsrc(eout + (size_t)img * Ho * Wo * a.cout, (unsigned)(Ho * Wo * a.cout) * 4u);
         const int oy = ty0 + 4 * (tl >> 4), ox = tx0 + 2 * (tl & 15);
         const int cbyte = (ct * 32 + 4 * q8) * 4;
-        const bool colok0 = ox < a.W, colok1 = ox + 1 < a.W;
+        const bool colok0 = ox < eW, colok1 = ox + 1 < eW;
         f32x4 y[4][2], P[4][4];
 #pragma unroll
         for (int ap = 0; ap < 4; ++ap)
@@ -249,18 +270,18 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 const int r0 = oy + 2 * h2;
                 f32x4 v = y[2 * h2][0];
                 if (colok1) v = max4(v, y[2 * h2][1]);
-                if (r0 + 1 < a.H) {
+                if (r0 + 1 < eH) {
                     v = max4(v, y[2 * h2 + 1][0]);
                     if (colok1) v = max4(v, y[2 * h2 + 1][1]);
                 }
                 const int off = (((r0 >> 1) * Wo + (ox >> 1)) * a.cout) * 4 + cbyte;
-                buf_store4(dst, v, (r0 < a.H && colok0) ? off : 0x7fffffff);
+                buf_store4(dst, v, (r0 < eH && colok0) ? off : 0x7fffffff);
             }
         } else {
 #pragma unroll
             for (int ap = 0; ap < 4; ++ap) {
-                const int off = (((oy + ap) * a.W + ox) * a.cout) * 4 + cbyte;
-                const bool rowok = oy + ap < a.H;
+                const int off = (((oy + ap) * eW + ox) * a.cout) * 4 + cbyte;
+                const bool rowok = oy + ap < eH;
                 buf_store4(dst, y[ap][0], (rowok && colok0) ? off : 0x7fffffff);
                 buf_store4(dst, y[ap][1], (rowok && colok1) ? off + a.cout * 4 : 0x7fffffff);
             }
@@ -420,8 +441,10 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
             for (;;) {
                 // the tile after this one (or this one again when the list is exhausted: its loads are then never consumed)
                 const int nitem = item + stride < hi ? item + stride : item;
-                const int nct_ = nitem % nct, nr = nitem / nct, npt = nr % tiles, nimg = nr / tiles;
-                const int ntx0 = (npt % a.tiles_x) * 32, nty0 = (npt / a.tiles_x) * 8;
+                const int nseg = seg_of(nitem);
+                const int nli = nitem - m.s[nseg].item0, ngtx = m.s[nseg].tiles_x, ntiles = ngtx * m.s[nseg].tiles_y;
+                const int nct_ = nli % nct, nr = nli / nct, npt = nr % ntiles, nimg = nr / ntiles;
+                const int ntx0 = (npt % ngtx) * 32, nty0 = (npt / ngtx) * 8;
                 const int wso_next = ((nct_ * 4 + wj) * nch) * 6144;
                 if (prio_mode) {
                     if ((ntile + (int)((blockIdx.x >> 3) >= (stride >> 1))) & 1) __builtin_amdgcn_s_setprio(1);
@@ -432,8 +455,8 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 // nst-3, or by the tile's entry code when nst == 2) the offsets switch to the next tile (loop tail, so that no
                 // branch splits the two chunks of a stage)
                 auto next_halo = [&]() {
-                    halo_offsets(ntx0, nty0);
-                    src = make_rsrc(a.in + nimg * src_img, src_bytes);
+                    halo_offsets(ntx0, nty0, m.s[nseg].H, m.s[nseg].W, m.s[nseg].Ws);
+                    src = src_of(m.s[nseg].in, m.s[nseg].Hs, m.s[nseg].Ws, nimg);
                 };
                 if (nst == 2) next_halo();
                 for (int s = 0; s + 1 < nst; ++s) {
@@ -451,7 +474,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 epilogue();                                     // of (ct, img, tx0, ty0); also writes the next tile's first halo stage
                 if (item + stride >= hi) break;
                 item += stride;
-                ct = nct_; img = nimg; tx0 = ntx0; ty0 = nty0;
+                ct = nct_; img = nimg; tx0 = ntx0; ty0 = nty0; seg = nseg;
 #pragma unroll
                 for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -499,13 +522,13 @@ int launch_pack_wino4(const float* w, float* p, int cin, int cout, hipStream_t s
     return check_launch("pack_wino4");
 }
 
-int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
-    ConvArgs a = a0;
+static int check_wino4_shape(const ConvArgs& a, int src_mode) {
     if (a.cin % W4_KR || a.cin < W4_KR) { set_error("conv3x3_wino4: cin %d not a multiple of 16", a.cin); return -1; }
     if (a.cout % 32) { set_error("conv3x3_wino4: cout %d not a multiple of 32", a.cout); return -1; }
     if (a.H < 2 || a.W < 2 || a.n < 1) { set_error("conv3x3_wino4: H, W must be >= 2, got %dx%d", a.H, a.W); return -1; }
     if ((size_t)a.Hs * a.Ws * a.cin * 4 >= 0x7fffffffULL || (size_t)a.H * a.W * a.cout * 4 >= 0x7fffffffULL) {
-        set_error("conv3x3_wino4: per-image tensors must stay below 2 GiB");
+        set_error("conv3x3_wino4: per-image tensors must stay below 2 GiB (32-bit buffer offsets): %dx%d with %d / %d channels", a.H, a.W,
+                  a.cin, a.cout);
         return -1;
     }
     if ((size_t)a.cin * a.cout * 96 >= 0xffffffffULL) { set_error("conv3x3_wino4: packed weights must stay below 4 GiB"); return -1; }
@@ -517,6 +540,19 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
         set_error("conv3x3_wino4: unsupported src_mode %d", src_mode);
         return -1;
     }
+    return 0;
+}
+
+static long long persistent_grid() {
+    const int cus = device_cu_count();
+    if (cus <= 0) return 0;
+    long long pgrid = 2LL * cus;
+    return pgrid - pgrid % 8;
+}
+
+int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
+    ConvArgs a = a0;
+    if (check_wino4_shape(a, src_mode)) return -1;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + 7) / 8;
     const long long blocks = (long long)a.tiles_x * a.tiles_y * (a.cout / 32) * a.n;
@@ -524,35 +560,83 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     static const int order_env = getenv("ADAIN_W4_ORDER") ? atoi(getenv("ADAIN_W4_ORDER")) : 1;
     a.xcd_order = order_env;
     const dim3 g((unsigned)blocks);
-    static const int diag_env = getenv("ADAIN_W4_DIAG") ? atoi(getenv("ADAIN_W4_DIAG")) : 0;
     // persistent form (default) whenever the launch has at least two tiles per resident workgroup; ADAIN_W4_PERSIST = largest
     // cin it is used for (0 = never: one tile per workgroup).  +2-3 % on most layer shapes, +1.1 % on the config-2 step.
     static const int persist_env = getenv("ADAIN_W4_PERSIST") ? atoi(getenv("ADAIN_W4_PERSIST")) : 1 << 20;
     static const int prio_env = getenv("ADAIN_W4_PRIO") ? atoi(getenv("ADAIN_W4_PRIO")) : 1;
-    const int cus = device_cu_count();
-    if (cus <= 0) { set_error("conv3x3_wino4: device query failed"); return -1; }
-    long long pgrid = 2LL * cus;
-    pgrid -= pgrid % 8;
+    const long long pgrid = persistent_grid();
+    if (pgrid <= 0) { set_error("conv3x3_wino4: device query failed"); return -1; }
     const bool persist = !a.dbg && a.cin <= persist_env && a.cin >= 2 * W4_KR && pgrid >= 8 && blocks >= 2 * pgrid;
     const int items = (int)blocks;
+    ConvSegs m{};
+    m.count = 1;
+    m.s[0] = ConvSeg{a.in, a.out, a.n, a.H, a.W, a.Hs, a.Ws, a.tiles_x, a.tiles_y, 0};
     if (persist) {
         const dim3 pg((unsigned)pgrid);
-        if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true>), pg, dim3(256), 0, s, a, items, prio_env);
-        else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, true>), pg, dim3(256), 0, s, a, items, prio_env);
-    } else if (a.dbg && diag_env == 2 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 2>), g, dim3(256), 0, s, a, items, 0);
-    else if (a.dbg && diag_env == 3 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 3>), g, dim3(256), 0, s, a, items, 0);
-    else if (a.dbg && diag_env == 5 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 5>), g, dim3(256), 0, s, a, items, 0);
-    else if (a.dbg && diag_env == 6 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 6>), g, dim3(256), 0, s, a, items, 0);
-    else if (a.dbg && diag_env == 7 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 7>), g, dim3(256), 0, s, a, items, 0);
-    else if (a.dbg && diag_env == 8 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 8>), g, dim3(256), 0, s, a, items, 0);
-    else if (a.dbg && diag_env == 12 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 12>), g, dim3(256), 0, s, a, items, 0);
-    else if (a.dbg && diag_env == 10 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 10>), g, dim3(256), 0, s, a, items, 0);
-    else if (a.dbg && diag_env == 11 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 11>), g, dim3(256), 0, s, a, items, 0);
-    else if (a.dbg && diag_env == 9 && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 9>), g, dim3(256), 0, s, a, items, 0);
-    else if (a.dbg && src_mode == SRC_DIRECT) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 1>), g, dim3(256), 0, s, a, items, 0);
-    else if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X>), g, dim3(256), 0, s, a, items, 0);
-    else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a, items, 0);
+        if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true>), pg, dim3(256), 0, s, a, m, items, prio_env);
+        else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, true>), pg, dim3(256), 0, s, a, m, items, prio_env);
+        return check_launch("conv3x3_wino4");
+    }
+#ifdef ADAIN_DIAG
+    // timing / stamp builds of the one-tile form (tools/ only: libadain_hip_diag.so); selected by ADAIN_W4_DIAG when a stamp
+    // buffer is set
+    static const int diag_env = getenv("ADAIN_W4_DIAG") ? atoi(getenv("ADAIN_W4_DIAG")) : 0;
+    if (a.dbg && src_mode == SRC_DIRECT) {
+        switch (diag_env) {
+#define W4_DIAG_CASE(D) case D: hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, D>), g, dim3(256), 0, s, a, m, items, 0); break;
+            W4_DIAG_CASE(2) W4_DIAG_CASE(3) W4_DIAG_CASE(5) W4_DIAG_CASE(6) W4_DIAG_CASE(7) W4_DIAG_CASE(8) W4_DIAG_CASE(9)
+            W4_DIAG_CASE(10) W4_DIAG_CASE(11) W4_DIAG_CASE(12)
+#undef W4_DIAG_CASE
+            default: hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 1>), g, dim3(256), 0, s, a, m, items, 0);
+        }
+        return check_launch("conv3x3_wino4(diag)");
+    }
+#endif
+    if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X>), g, dim3(256), 0, s, a, m, items, 0);
+    else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a, m, items, 0);
     return check_launch("conv3x3_wino4");
+}
+
+int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int count, int src_mode, hipStream_t s) {
+    if (count < 1 || count > MAX_CONV_SEGS) { set_error("conv3x3_wino4_multi: 1..%d segments, got %d", MAX_CONV_SEGS, count); return -1; }
+    ConvSegs m{};
+    m.count = count;
+    long long total = 0;
+    ConvArgs a = layer;
+    for (int i = 0; i < count; ++i) {
+        a.in = segs[i].in; a.out = segs[i].out; a.n = segs[i].n;
+        a.H = segs[i].H; a.W = segs[i].W; a.Hs = segs[i].Hs; a.Ws = segs[i].Ws;
+        if (!a.in || !a.out) { set_error("conv3x3_wino4_multi: null pointer in segment %d", i); return -1; }
+        if (check_wino4_shape(a, src_mode)) return -1;
+        m.s[i] = segs[i];
+        m.s[i].tiles_x = (a.W + 31) / 32;
+        m.s[i].tiles_y = (a.H + 7) / 8;
+        m.s[i].item0 = (int)total;
+        total += (long long)m.s[i].tiles_x * m.s[i].tiles_y * (a.cout / 32) * a.n;
+        if (total > 0x7fffffffLL) { set_error("conv3x3_wino4_multi: too many tiles"); return -1; }
+    }
+    static const int merge_env = getenv("ADAIN_W4_MERGE") ? atoi(getenv("ADAIN_W4_MERGE")) : 1;
+    static const int prio_env = getenv("ADAIN_W4_PRIO") ? atoi(getenv("ADAIN_W4_PRIO")) : 1;
+    const long long pgrid = persistent_grid();
+    if (pgrid <= 0) { set_error("conv3x3_wino4: device query failed"); return -1; }
+    if (count == 1 || !merge_env || a.cin < 2 * W4_KR || pgrid < 8 || total < 2 * pgrid) {
+        // not enough work for a shared persistent list (or a single segment): one launch per segment
+        for (int i = 0; i < count; ++i) {
+            a.in = segs[i].in; a.out = segs[i].out; a.n = segs[i].n;
+            a.H = segs[i].H; a.W = segs[i].W; a.Hs = segs[i].Hs; a.Ws = segs[i].Ws;
+            if (int r = launch_conv3x3_wino4(a, src_mode, s)) return r;
+        }
+        return 0;
+    }
+    // the kernel reads its geometry from the segments; the ConvArgs copy carries the layer (weights, bias, cin, cout, flags)
+    a.in = m.s[0].in; a.out = m.s[0].out; a.n = m.s[0].n; a.H = m.s[0].H; a.W = m.s[0].W; a.Hs = m.s[0].Hs; a.Ws = m.s[0].Ws;
+    a.tiles_x = m.s[0].tiles_x; a.tiles_y = m.s[0].tiles_y;
+    a.xcd_order = 1;
+    a.dbg = nullptr;
+    const dim3 pg((unsigned)pgrid);
+    if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true>), pg, dim3(256), 0, s, a, m, (int)total, prio_env);
+    else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, true>), pg, dim3(256), 0, s, a, m, (int)total, prio_env);
+    return check_launch("conv3x3_wino4(multi)");
 }
 
 }  // namespace adain

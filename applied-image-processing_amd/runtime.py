@@ -30,6 +30,9 @@ SIGNATURES = {
     "adain_encoded_size": (None, [_c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "adain_encode_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "adain_encode": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_int, _c_int, _PP, _c_void_p]),
+    "adain_encode_multi_workspace_bytes": (_c_size_t, [_c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
+    "adain_encode_multi": (_c_int, [_c_int, _PP, _PP, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), _c_void_p,
+                                    _c_void_p, _c_size_t, _PP, _c_void_p]),
     "adain_decode_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "adain_decode": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_int, _c_int, _PP, _c_void_p]),
     "adain_mean_std_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
@@ -188,6 +191,34 @@ def encode(image, packed, events=None):
         _check(lib().adain_encode(image.data_ptr(), feat.data_ptr(), packed.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, ev,
                                   _stream()), "adain_encode")
     return feat
+
+
+def encode_multi(images, packed, events=None):
+    """Several image batches [n_i,3,h_i,w_i] of different sizes through the encoder in one pass (the content batch and the
+    style image of one style_transfer call) -> list of relu4_1 features NHWC; bit-identical to ``encode`` per batch."""
+    images = [_dev(x, "image") for x in images]
+    for x in images:
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise AdainHipError(f"encode: expected [n,3,h,w], got {tuple(x.shape)}")
+        if x.device != images[0].device:
+            raise AdainHipError("encode_multi: all image batches must be on one device")
+    k = len(images)
+    IntArr = _c_int * k
+    n, h, w = IntArr(*[x.shape[0] for x in images]), IntArr(*[x.shape[2] for x in images]), IntArr(*[x.shape[3] for x in images])
+    feats = []
+    for x in images:
+        hc, wc = encoded_size(x.shape[2], x.shape[3])
+        feats.append(torch.empty((x.shape[0], hc, wc, 512), dtype=torch.float32, device=x.device))
+    nbytes = lib().adain_encode_multi_workspace_bytes(k, n, h, w)
+    if nbytes == 0:
+        raise AdainHipError(f"encode_multi: 1..4 image batches per call, got {k}")
+    ws = workspace(images[0].device, "conv", nbytes)
+    ip, _k1 = _ptr_array(images)
+    fp, _k2 = _ptr_array(feats)
+    ev, _keep = _event_array(events)
+    with torch.cuda.device(images[0].device):
+        _check(lib().adain_encode_multi(k, ip, fp, n, h, w, packed.data_ptr(), ws.data_ptr(), ws.numel(), ev, _stream()), "adain_encode_multi")
+    return feats
 
 
 def decode(feat, packed, events=None):

@@ -204,14 +204,14 @@ class Step:
             return out
 
         b = enc(self.batch, self.h, self.w)
-        if self.style_each_step:
-            b += enc(1, self.hs, self.ws)
+        if self.style_each_step:      # content and style share one launch per encoder layer (adain_encode_multi)
+            b = [x + y - 4 * 9 * L["cin"] * L["cout"] for x, y, L in zip(b, enc(1, self.hs, self.ws), arch.encoder_plan()[2:])]
         return b + dec(self.batch, self.hc, self.wc)
 
     def conv3x3_flops(self):
         f = enc_conv3x3_flops(self.batch, self.h, self.w)
         if self.style_each_step:
-            f += enc_conv3x3_flops(1, self.hs, self.ws)
+            f = [x + y for x, y in zip(f, enc_conv3x3_flops(1, self.hs, self.ws))]
         return f + dec_conv3x3_flops(self.batch, self.hc, self.wc)
 
     def run(self, timed=False, to_u8=False):
@@ -224,18 +224,18 @@ class Step:
         px = n * self.h * self.w
         feat_bytes = n * hc * wc * 512 * 4
         ev_c = make_events(11) if timed else None
-        cf = rt.encode(self.content, self.enc, ev_c)
+        if self.style_each_step:
+            # content and style through the encoder in one pass (what style_transfer / style_transfer_simple do): one launch per layer
+            cf, sf = rt.encode_multi([self.content, self.style], self.enc, ev_c)
+            s_mean, s_std = rt.mean_std(sf, True)
+            first_px = px + self.hs * self.ws
+        else:
+            cf = rt.encode(self.content, self.enc, ev_c)
+            s_mean, s_std = self.s_mean, self.s_std
+            first_px = px
         if timed:
             ev += [(ev_c[i + 1], ev_c[i + 2]) for i in range(8)]
-            self.edge_ev.append(("conv_first_kernel (content: NCHW image -> 64-ch NHWC)", px * (12 + 256), ev_c[0], ev_c[1]))
-        if self.style_each_step:
-            ev_s = make_events(11) if timed else None
-            sf = rt.encode(self.style, self.enc, ev_s)
-            s_mean, s_std = rt.mean_std(sf, True)
-            if timed:
-                ev += [(ev_s[i + 1], ev_s[i + 2]) for i in range(8)]
-        else:
-            s_mean, s_std = self.s_mean, self.s_std
+            self.edge_ev.append(("conv_first_kernel (NCHW image -> 64-ch NHWC)", first_px * (12 + 256), ev_c[0], ev_c[1]))
         c_mean, c_std = T("mean_std_nhwc_partial + finalize (content relu4_1)", feat_bytes, rt.mean_std, cf, True)
         if self.config == 3:
             p = torch.cat([T("bicubic_minmax + strength_sum + strength_apply (P map)", self.h * self.w * 4 + hc * wc * 12,

@@ -60,6 +60,16 @@ size_t adain_encode_workspace_bytes(int n, int h, int w);
 int adain_encode(const float* image_nchw, float* feat_nhwc, const float* packed, void* workspace,
                  size_t workspace_bytes, int n, int h, int w, void* const* layer_events, adain_stream_t stream);
 
+/* The same encoder over `count` (1..4) image batches of different sizes in ONE pass: the content batch and the style image
+ * of a style_transfer call go through the same vgg (test.py:57,63 / :76-77).  Results are bit-identical to one adain_encode
+ * per batch; every generic 3x3 layer is a single launch whose tile list covers all batches, so the small style-branch layers
+ * ride in the content launches instead of under-filling the chip on their own.  images[i] NCHW [n[i]][3][h[i]][w[i]] ->
+ * feats[i] NHWC.  The pointer arrays and n / h / w are HOST arrays.  layer_events as for adain_encode. */
+size_t adain_encode_multi_workspace_bytes(int count, const int* n, const int* h, const int* w);
+int adain_encode_multi(int count, const float* const* images_nchw, float* const* feats_nhwc, const int* n, const int* h,
+                       const int* w, const float* packed, void* workspace, size_t workspace_bytes,
+                       void* const* layer_events, adain_stream_t stream);
+
 /* ---- decoder: net.decoder(feat) (net.py:6-36; test.py:71,81) ----------------------------------------
  * feat NHWC [n][hc][wc][512] -> image NCHW [n][3][8hc][8wc].  layer_events: 10 events (before + 9 convs). */
 size_t adain_decode_workspace_bytes(int n, int hc, int wc);

@@ -490,3 +490,20 @@ def test_statistics_edge_cases(rt):
     for size in ((600, 1000), (37, 61)):
         p = rt.strength_map(d.cuda(), size[0], size[1], 0.1, 15.0)
         close(p, O.compute_stylization_strength_map(d, size, 0.1, 15.0), 1e-4, 3e-5)
+
+
+@pytest.mark.parametrize("sizes", [((1, 1000, 1016), (1, 500, 333)), ((2, 520, 392), (1, 264, 200), (1, 90, 70)), ((1, 64, 64), (1, 48, 80))])
+def test_encode_multi_is_bitwise_the_separate_encodes(rt, weights, sizes):
+    """adain_encode_multi: content batch and style image through the encoder in one pass, every 3x3 layer one launch whose tile
+    list covers all segments (persistent kernel) - or one launch per segment when the work is too small.  Same tiles, same
+    arithmetic: the features must equal the separate adain_encode results bit for bit (which are checked against the oracle)."""
+    vgg_sd, _ = weights
+    packed = rt.pack_encoder(vgg_sd, torch.device("cuda", 0))
+    xs = [T(synth.image(800 + i, n, h, w)).cuda() for i, (n, h, w) in enumerate(sizes)]
+    multi = rt.encode_multi(xs, packed)
+    for x, f in zip(xs, multi):
+        assert torch.equal(f, rt.encode(x, packed))
+    with torch.no_grad():
+        close(multi[-1].permute(0, 3, 1, 2), O.encode(vgg_sd, xs[-1].cpu()))
+    with pytest.raises(rt.AdainHipError):
+        rt.encode_multi(xs + xs + xs, packed)                     # more than four segments
