@@ -31,7 +31,7 @@ static const Layer DEC[8] = {{512, 256, SRC_DIRECT, 0}, {256, 256, SRC_UP2X, 0},
                              {256, 128, SRC_DIRECT, 0}, {128, 128, SRC_UP2X, 0},   {128, 64, SRC_DIRECT, 0},  {64, 64, SRC_UP2X, 0}};
 
 static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
-constexpr size_t FIRST_W = 2 * 4 * 64 * 4, FIRST_B = 64, LAST_W = 4 * 9 * 4 * 4 * 3, LAST_B = 3;
+constexpr size_t FIRST_W = 2 * 5 * 64 * 4, FIRST_B = 64, LAST_W = 4 * 9 * 4 * 4 * 3, LAST_B = 3;
 
 // packed layout: [first w][first b] then per generic layer [w direct][b][w F(2x2,3x3)][w F(4,3)xF(2,3)], every block
 // 256-B aligned.  All three weight forms are kept (28 + 50 + 75 MB): the F(4,3) x F(2,3) Winograd kernel is the default for

@@ -58,23 +58,23 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
 
 // conv0 (1x1, 3->3, net.py:39) folded into conv1_1 (3->64, net.py:41): a pointwise conv commutes
 // with reflection padding, so W'[o][c][t] = sum_c' W1[o][c'][t] W0[c'][c] and
-// b'[o] = b1[o] + sum_{c',t} W1[o][c'][t] b0[c'].  K index k = tap*3 + c (27 real, padded to 32).
-// packed: [2 cout tiles][4 groups][64 lanes][4] with k = 8 g + 4 h + s.
+// b'[o] = b1[o] + sum_{c',t} W1[o][c'][t] b0[c'].  K index k = 4 tap + c over 10 taps x (r, g, b, 0): the fourth
+// "channel" and the tenth tap are zero padding, so that one b128 LDS read of an [r, g, b, 0] halo pixel is one tap's K-slice.
+// packed (A operand = weights): [2 cout tiles][5 groups][64 lanes][4] with tap = 2 g + h, c = s.
 __global__ void pack_conv_first_kernel(const float* __restrict__ w0, const float* __restrict__ b0,
                                        const float* __restrict__ w1, const float* __restrict__ b1,
                                        float* __restrict__ p, float* __restrict__ bias_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 2 * 4 * 64 * 4) {
+    if (i < 2 * 5 * 64 * 4) {
         int r = i;
         const int s = r & 3; r >>= 2;
         const int lane = r & 63; r >>= 6;
-        const int g = r & 3; r >>= 2;
+        const int g = r % 5; r /= 5;
         const int T = r;
         const int j = lane & 31, h = lane >> 5;
-        const int o = T * 32 + j, k = g * 8 + h * 4 + s;
+        const int o = T * 32 + j, tap = 2 * g + h, c = s;
         float v = 0.f;
-        if (k < 27) {
-            const int tap = k / 3, c = k % 3;
+        if (tap < 9 && c < 3) {
             for (int cp = 0; cp < 3; ++cp) v += w1[(o * 3 + cp) * 9 + tap] * w0[cp * 3 + c];
         }
         p[i] = v;
@@ -624,81 +624,96 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_persist_kernel(ConvAr
 }
 
 // ---------------------------------------------------------------------------------------------
-// First layer: conv0 (1x1) folded into conv1_1 (3 -> 64), NCHW image in, NHWC out, ReLU.
-// im2col of the 8x32 tile into LDS ([256 px][32 k], stride 36 floats), then 4 k-groups of MFMA.
+// First layer: conv0 (1x1) folded into conv1_1 (3 -> 64), NCHW image in, NHWC out, ReLU.  HBM-bound: 12 B read and 256 B
+// written per pixel, so the kernel is built around its stores.
+//   * the reflect-padded 10 x 34 halo of an 8 x 32 pixel tile is staged once as [r, g, b, 0] pixels (at most 6 coalesced
+//     scalar loads per thread instead of 27 gathered ones);
+//   * MFMA with A = weights, B = pixels: a tap's K-slice is ONE b128 LDS read of a halo pixel (K = 10 taps x 4, the padding
+//     multiplies zero weights), and a lane ends up holding 4 consecutive channels of one pixel;
+//   * each wave passes its two output rows through a private LDS row buffer so that every store instruction writes 1 KiB of
+//     contiguous NHWC memory (4 pixels x 64 channels, b128 per lane): 16 store instructions per wave and tile, where the
+//     accumulator layout itself would need 64 dword stores.
 // ---------------------------------------------------------------------------------------------
+constexpr int CF_OSTR = 68;      // floats per pixel of the row buffer: b128 writes of 8 consecutive pixels cover all 32 banks
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ img_nchw,
                                                          float* __restrict__ out, const float* __restrict__ wpk,
                                                          const float* __restrict__ bias, int H, int W, int tiles_x,
                                                          int tiles_y) {
-    constexpr int S = 36;
-    __shared__ __attribute__((aligned(16))) float smem[256 * S];
+    constexpr int HALO = 10 * 34;
+    // the halo image (5.4 KiB) and the four waves' row buffers (4 x 8.5 KiB) share the allocation: 34 KiB, 4 workgroups per CU
+    __shared__ __attribute__((aligned(16))) float smem[4 * 32 * CF_OSTR];
+    static_assert(HALO * 4 <= 4 * 32 * CF_OSTR, "LDS layout");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    int bid = blockIdx.x;
     const int tiles = tiles_x * tiles_y;
-    const int pt = bid % tiles;
-    const int img = bid / tiles;
+    const int pt = blockIdx.x % tiles;
+    const int img = blockIdx.x / tiles;
     const int tx0 = (pt % tiles_x) * 32, ty0 = (pt / tiles_x) * 8;
     const float* __restrict__ src = img_nchw + (size_t)img * 3 * H * W;
+    const size_t plane = (size_t)H * W;
 
-    {
-        const int py = tid >> 5, px = tid & 31;
-        float v[32];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int y = reflect1(ty0 + py + t / 3 - 1, H), x = reflect1(tx0 + px + t % 3 - 1, W);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) v[t * 3 + c] = src[((size_t)c * H + y) * W + x];
-        }
-#pragma unroll
-        for (int k = 27; k < 32; ++k) v[k] = 0.f;
-        float* d = smem + tid * S;
-#pragma unroll
-        for (int k = 0; k < 32; k += 4) *(f32x4*)(d + k) = f32x4{v[k], v[k + 1], v[k + 2], v[k + 3]};
+    for (int p = tid; p < HALO; p += 256) {
+        const int hy = p / 34, hx = p - hy * 34;
+        const int y = reflect1(ty0 + hy - 1, H), x = reflect1(tx0 + hx - 1, W);
+        const float* __restrict__ q = src + (size_t)y * W + x;
+        *(f32x4*)(smem + p * 4) = f32x4{q[0], q[plane], q[2 * plane], 0.f};
     }
     __syncthreads();
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2];      // [channel tile][row of this wave]
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
 
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 af[2], bf[2];
+    for (int g = 0; g < 5; ++g) {
+        const int tap = min(2 * g + lh, 8);          // the tenth tap carries zero weights: any halo pixel will do
+        const int ty = tap / 3, tx = tap - ty * 3;
+        f32x4 wf[2], xf[2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) af[m] = *(const f32x4*)(smem + ((wave * 2 + m) * 32 + li) * S + g * 8 + lh * 4);
+        for (int t = 0; t < 2; ++t) wf[t] = *(const f32x4*)(wpk + ((t * 5 + g) * 64 + lane) * 4);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) bf[n] = *(const f32x4*)(wpk + ((n * 4 + g) * 64 + lane) * 4);
+        for (int m = 0; m < 2; ++m) xf[m] = *(const f32x4*)(smem + ((wave * 2 + m + ty) * 34 + li + tx) * 4);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][s], bf[n][s], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < 2; ++m)
+                    acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[t][s], xf[m][s], acc[t][m], 0, 0, 0);
     }
+    __syncthreads();                                 // every wave has read its halo pixels: the row buffers may overwrite them
 
+    float* const st = smem + wave * (32 * CF_OSTR);
+    const rsrc_t dst = make_rsrc(out + (size_t)img * H * W * 64, (unsigned)((size_t)H * W * 256));
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int y = ty0 + wave * 2 + m;
-        if (y >= H) continue;
-        float* __restrict__ orow = out + ((size_t)img * H + y) * W * 64;
+        // lane (li, lh) holds channels 32 t + 8 q + 4 lh + (0..3) of pixel li in acc[t][m][4 q .. 4 q + 3]
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int co = n * 32 + li;
-            const float b = bias[co];
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int x = tx0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (x < W) orow[(size_t)x * 64 + co] = fmaxf(acc[m][n][r] + b, 0.f);
+            for (int q = 0; q < 4; ++q) {
+                const int ch = 32 * t + 8 * q + 4 * lh;
+                const f32x4 b4 = *(const f32x4*)(bias + ch);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[t][m][4 * q + e] + b4[e], 0.f);
+                *(f32x4*)(st + li * CF_OSTR + ch) = v;
             }
+        // the row buffer is private to the wave and LDS operations of one wave complete in order: no barrier
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = k * 64 + lane, px = idx >> 4, q16 = idx & 15;
+            const f32x4 v = *(const f32x4*)(st + px * CF_OSTR + q16 * 4);
+            const int x = tx0 + px;
+            const int off = ((y * W + x) * 64 + q16 * 4) * 4;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, (y < H && x < W) ? off : 0x7fffffff, 0, 0);
         }
     }
 }
@@ -709,15 +724,17 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 // output pixel, inputs from the same LDS halo image as the MFMA kernel (conflict-free b128 reads),
 // weights wave-uniform (scalar loads).
 // ---------------------------------------------------------------------------------------------
-template <bool DBUF>
+// R output rows per thread (tile = 8 R rows x 32 pixels): the halo of a taller tile is a smaller share of what the workgroup
+// reads ((8R + 2) x 34 / (8R x 32): 1.33 for R = 1, 1.20 for R = 2), and every wave-uniform weight feeds R pixels.
+template <bool DBUF, int R>
 __global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         const float* __restrict__ wpk, const float* __restrict__ bias,
                                                         int H, int W, int tiles_x, int tiles_y) {
-    constexpr int TH = 8, NTHR = 256, CIN = 64;
+    constexpr int TH = 8 * R, NTHR = 256, CIN = 64;
     using Stager = HaloStager<SRC_DIRECT, TH, NTHR>;
     constexpr int BUF = Stager::HALO * LSTR;
     // DBUF: two LDS buffers, the next chunk's loads overlap this chunk's FMAs (2 blocks per CU);
-    // !DBUF: one buffer, 5 blocks per CU hide the load latency by occupancy instead
+    // !DBUF: one buffer, several blocks per CU hide the load latency by occupancy instead
     __shared__ __attribute__((aligned(16))) float smem[(DBUF ? 2 : 1) * BUF];
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
@@ -734,7 +751,9 @@ __global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict_
     __syncthreads();
 
     const int py = tid >> 5, px = tid & 31;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    float acc[R][3];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.f;
     constexpr int NCH = CIN / KC;
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
@@ -750,13 +769,17 @@ __global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict_
                 const float* __restrict__ w = wc + (ty * 3 + tx) * 48;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = *(const f32x4*)(sp + q * 4);
+                    f32x4 v[R];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        acc0 = fmaf(v[s], w[q * 12 + s * 3 + 0], acc0);
-                        acc1 = fmaf(v[s], w[q * 12 + s * 3 + 1], acc1);
-                        acc2 = fmaf(v[s], w[q * 12 + s * 3 + 2], acc2);
-                    }
+                    for (int r = 0; r < R; ++r) v[r] = *(const f32x4*)(sp + r * 8 * HW_ * LSTR + q * 4);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            acc[r][0] = fmaf(v[r][s], w[q * 12 + s * 3 + 0], acc[r][0]);
+                            acc[r][1] = fmaf(v[r][s], w[q * 12 + s * 3 + 1], acc[r][1]);
+                            acc[r][2] = fmaf(v[r][s], w[q * 12 + s * 3 + 2], acc[r][2]);
+                        }
                 }
             }
         }
@@ -764,12 +787,16 @@ __global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict_
         if (more) st.store(smem + (DBUF ? ((c + 1) & 1) * BUF : 0), tid);
         __syncthreads();
     }
-    const int y = ty0 + py, x = tx0 + px;
-    if (y < H && x < W) {
-        float* __restrict__ o = out + (size_t)img * 3 * H * W + (size_t)y * W + x;
-        o[0] = acc0 + bias[0];
-        o[(size_t)H * W] = acc1 + bias[1];
-        o[(size_t)2 * H * W] = acc2 + bias[2];
+    const int x = tx0 + px;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int y = ty0 + py + 8 * r;
+        if (y < H && x < W) {
+            float* __restrict__ o = out + (size_t)img * 3 * H * W + (size_t)y * W + x;
+            o[0] = acc[r][0] + bias[0];
+            o[(size_t)H * W] = acc[r][1] + bias[1];
+            o[(size_t)2 * H * W] = acc[r][2] + bias[2];
+        }
     }
 }
 
@@ -786,7 +813,7 @@ int launch_pack_conv3x3(const float* w, float* p, int cin, int cout, hipStream_t
 
 int launch_pack_conv_first(const float* w0, const float* b0, const float* w1, const float* b1, float* p,
                            float* bias_out, hipStream_t s) {
-    hipLaunchKernelGGL(pack_conv_first_kernel, dim3(8), dim3(256), 0, s, w0, b0, w1, b1, p, bias_out);
+    hipLaunchKernelGGL(pack_conv_first_kernel, dim3(10), dim3(256), 0, s, w0, b0, w1, b1, p, bias_out);
     return check_launch("pack_conv_first");
 }
 
@@ -910,7 +937,9 @@ int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s) 
 int launch_conv_first(const float* img, float* out, const float* packed, const float* bias, int n, int H, int W,
                       hipStream_t s) {
     if (H < 2 || W < 2 || n < 1) { set_error("conv_first: H, W must be >= 2, got %dx%d", H, W); return -1; }
+    if ((size_t)H * W * 256 >= 0x7fffffffULL) { set_error("conv_first: a 64-channel image of %dx%d reaches 2 GiB (32-bit buffer offsets)", H, W); return -1; }
     const int tx = (W + 31) / 32, ty = (H + 7) / 8;
+    if ((long long)tx * ty * n > 0x7fffffffLL) { set_error("conv_first: bad grid"); return -1; }
     hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(tx * ty * n)), dim3(256), 0, s, img, out, packed, bias, H, W, tx, ty);
     return check_launch("conv_first");
 }
@@ -918,9 +947,18 @@ int launch_conv_first(const float* img, float* out, const float* packed, const f
 int launch_conv_last(const float* in, float* out, const float* packed, const float* bias, int n, int H, int W,
                      hipStream_t s) {
     if (H < 2 || W < 2 || n < 1) { set_error("conv_last: H, W must be >= 2, got %dx%d", H, W); return -1; }
+    if ((size_t)H * W * 256 >= 0x7fffffffULL) { set_error("conv_last: a 64-channel image of %dx%d reaches 2 GiB (32-bit buffer offsets)", H, W); return -1; }
     const int tx = (W + 31) / 32, ty = (H + 7) / 8;
-    // single-buffered: 78 us vs 107 us double-buffered at 1024x1024 (occupancy beats overlap for this HBM-bound kernel)
-    hipLaunchKernelGGL(conv_last_kernel<false>, dim3((unsigned)(tx * ty * n)), dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
+    if ((long long)tx * ty * n > 0x7fffffffLL) { set_error("conv_last: bad grid"); return -1; }
+    // single-buffered: 78 us vs 107 us double-buffered at 1024x1024 (occupancy beats overlap for this HBM-bound kernel);
+    // ADAIN_LAST_ROWS = output rows per thread (1: 8-row tiles, 2: 16-row tiles)
+    static const int rows_env = getenv("ADAIN_LAST_ROWS") ? atoi(getenv("ADAIN_LAST_ROWS")) : 2;
+    if (rows_env == 2 && H > 8) {
+        const int ty2 = (H + 15) / 16;
+        hipLaunchKernelGGL((conv_last_kernel<false, 2>), dim3((unsigned)(tx * ty2 * n)), dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty2);
+    } else {
+        hipLaunchKernelGGL((conv_last_kernel<false, 1>), dim3((unsigned)(tx * ty * n)), dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
+    }
     return check_launch("conv_last");
 }
 
