@@ -94,25 +94,33 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def _param_state(module):
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
 def _load_into(module, path, tag):
+    """Loads the checkpoint at ``path`` into the module-level singleton unless exactly this file version is what the module
+    currently holds: the cache entry also records the parameters' (storage, version) state after the load, so weights written
+    into ``net.vgg`` / ``net.decoder`` by anyone else (another ``load_state_dict``, ``.to()``, in-place edits) invalidate it and
+    results never depend on call order (the reference reloads on every call, test.py:183-184)."""
     p = Path(path)
     st = p.stat()
     key = (tag, str(p.resolve()), st.st_mtime_ns, st.st_size)
-    if _loaded.get(tag) != key:
+    if _loaded.get(tag) != (key, _param_state(module)):
         module.load_state_dict(torch.load(str(p), map_location="cpu"))
-        _loaded[tag] = key
+        _loaded[tag] = (key, _param_state(module))
 
 
 # ---------------------------------------------------------------------------------------------------------
 def _singletons(device, vgg_str=None, decoder_str=None):
     """The module-level encoder / decoder (net.vgg, net.decoder) in eval mode on ``device`` with the checkpoints at the
     given paths loaded (once per file version; the reference re-reads both files on every call, test.py:183-184)."""
-    enc, dec = net.vgg.eval(), net.decoder.eval()
+    enc, dec = net.vgg.eval().to(device), net.decoder.eval().to(device)     # move first: .to() replaces the parameter storages
     if vgg_str is not None:
         _load_into(enc, vgg_str, "vgg")
     if decoder_str is not None:
         _load_into(dec, decoder_str, "decoder")
-    return enc.to(device), dec.to(device)
+    return enc, dec
 
 
 def _as_batch(img, size, crop, device, rgb_only=False):

@@ -11,6 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libadain_hip.so")
+DIAG_LIB = os.path.join(PKG, "libadain_hip_diag.so")     # -DADAIN_DIAG: env tuning switches, stamp / timing-only kernels (tools/ only)
 SOURCES = ["conv.hip", "conv_wino.hip", "conv_wino3.hip", "conv_wino4.hip", "stats.hip", "pixel.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]
 # The MFMA kernels carry their fp32 vector-ALU work (input transform, epilogues) next to the matrix instructions, where
@@ -34,9 +35,13 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    objdir = os.path.join(PKG, "build")
+def build(force=False, verbose=False, diag=False):
+    """Builds the product library; ``diag=True`` builds ``libadain_hip_diag.so`` instead (same sources with -DADAIN_DIAG: the
+    environment tuning switches and the stamp / timing-only kernel variants used by tools/; load it with ADAIN_HIP_LIB=...)."""
+    objdir = os.path.join(PKG, "build_diag" if diag else "build")
     os.makedirs(objdir, exist_ok=True)
+    lib = DIAG_LIB if diag else LIB
+    flags = FLAGS + (["-DADAIN_DIAG"] if diag else [])
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_utils.h"), os.path.join(INC, "adain_hip.h")]
     hipcc = _hipcc()
     jobs = []
@@ -46,7 +51,7 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-I", INC, "-c", s, "-o", o])
+            jobs.append([hipcc] + flags + EXTRA_FLAGS.get(src, []) + ["-I", INC, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -60,10 +65,10 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _newer(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if force or jobs or _newer(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

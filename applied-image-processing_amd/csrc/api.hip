@@ -33,11 +33,26 @@ static const Layer DEC[8] = {{512, 256, SRC_DIRECT, 0}, {256, 256, SRC_UP2X, 0},
 static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
 constexpr size_t FIRST_W = 2 * 5 * 64 * 4, FIRST_B = 64, LAST_W = 4 * 9 * 4 * 4 * 3, LAST_B = 3;
 
-// packed layout: [first w][first b] then per generic layer [w direct][b][w F(2x2,3x3)][w F(4,3)xF(2,3)], every block
-// 256-B aligned.  All three weight forms are kept (28 + 50 + 75 MB): the F(4,3) x F(2,3) Winograd kernel is the default for
-// every generic 3x3 layer; ADAIN_WINO_MH selects the F(2x2,3x3) kernels, ADAIN_WINOGRAD=0 the direct implicit GEMM (A/B
-// runs, bit-different but equally valid).
-struct Offsets { size_t w[8], b[8], ww[8], w4[8], first_b, last_w, last_b, total; };
+// Which form of the generic 3x3 layers the encoder / decoder schedules run.  The product library always runs the Winograd
+// F(4,3) x F(2,3) kernels (FORM_WINO4); the diagnostic build (-DADAIN_DIAG) can select the others for A/B runs:
+// ADAIN_WINOGRAD=0 -> direct implicit GEMM, ADAIN_WINO_MH=34 / 3 / 4 / 1 / 2 -> F(2x2,3x3) kernels (bit-different, equally
+// valid results; all forms stay reachable and tested through adain_conv3x3 / adain_conv3x3_wino).
+enum { FORM_DIRECT = 0, FORM_WINO2 = 1, FORM_WINO4 = 2 };
+static int wino_mh() {
+    // 5 (default): F(4,3) x F(2,3); F(2x2,3x3) forms: 34 = persistent form (4) where the K loop is short (cin <= 64) and
+    // register-resident-A form (3) elsewhere; 1, 2: LDS V image forms
+    static const int mh = tune_env("ADAIN_WINO_MH", 5);
+    return mh;
+}
+static int conv_form() {
+    static const int form = tune_env("ADAIN_WINOGRAD", 1) == 0 ? FORM_DIRECT : (wino_mh() == 5 ? FORM_WINO4 : FORM_WINO2);
+    return form;
+}
+static size_t form_floats(int cin, int cout) { return (size_t)cin * cout * (conv_form() == FORM_WINO4 ? 24 : conv_form() == FORM_WINO2 ? 16 : 9); }
+
+// packed layout: [first w][first b] then per generic layer [w in the form the schedules launch][b], every block 256-B
+// aligned: 75 MB for the two networks in the F(4,3) x F(2,3) form (only that form is packed and kept).
+struct Offsets { size_t w[8], b[8], first_b, last_w, last_b, total; };
 static Offsets enc_offsets() {
     Offsets f{};
     size_t o = 0;
@@ -46,13 +61,9 @@ static Offsets enc_offsets() {
     o += align64(FIRST_B);
     for (int i = 0; i < 8; ++i) {
         f.w[i] = o;
-        o += align64((size_t)ENC[i].cin * ENC[i].cout * 9);
+        o += align64(form_floats(ENC[i].cin, ENC[i].cout));
         f.b[i] = o;
         o += align64(ENC[i].cout);
-        f.ww[i] = o;
-        o += align64((size_t)ENC[i].cin * ENC[i].cout * 16);
-        f.w4[i] = o;
-        o += align64((size_t)ENC[i].cin * ENC[i].cout * 24);
     }
     f.total = o;
     return f;
@@ -62,13 +73,9 @@ static Offsets dec_offsets() {
     size_t o = 0;
     for (int i = 0; i < 8; ++i) {
         f.w[i] = o;
-        o += align64((size_t)DEC[i].cin * DEC[i].cout * 9);
+        o += align64(form_floats(DEC[i].cin, DEC[i].cout));
         f.b[i] = o;
         o += align64(DEC[i].cout);
-        f.ww[i] = o;
-        o += align64((size_t)DEC[i].cin * DEC[i].cout * 16);
-        f.w4[i] = o;
-        o += align64((size_t)DEC[i].cin * DEC[i].cout * 24);
     }
     f.last_w = o;
     o += align64(LAST_W);
@@ -78,32 +85,26 @@ static Offsets dec_offsets() {
     return f;
 }
 
-static bool use_winograd() {
-    static const bool on = !(getenv("ADAIN_WINOGRAD") && atoi(getenv("ADAIN_WINOGRAD")) == 0);
-    return on;
-}
-
-static int wino_mh() {
-    // 5 (default): F(4,3) x F(2,3); F(2x2,3x3) forms: 34 = persistent form (4) where the K loop is short (cin <= 64) and
-    // register-resident-A form (3) elsewhere; 1, 2: LDS V image forms
-    static const int mh = getenv("ADAIN_WINO_MH") ? atoi(getenv("ADAIN_WINO_MH")) : 5;
-    return mh;
+static int pack_layer(const float* w, float* dst, int cin, int cout, hipStream_t s) {
+    switch (conv_form()) {
+        case FORM_WINO4: return launch_pack_wino4(w, dst, cin, cout, s);
+        case FORM_WINO2: return launch_pack_wino(w, dst, cin, cout, s);
+        default: return launch_pack_conv3x3(w, dst, cin, cout, s);
+    }
 }
 
 static int launch_layer(ConvArgs& a, const float* packed, const Offsets& f, int i, int src, hipStream_t s) {
     a.bias = packed + f.b[i];
-    if (use_winograd() && src != SRC_POOL2) {
-        a.wpk = packed + f.ww[i];
-        int mh = wino_mh();
-        if (mh == 5) {
-            a.wpk = packed + f.w4[i];
-            return launch_conv3x3_wino4(a, src, s);
-        }
-        if (mh == 34) mh = a.cin <= 64 ? 4 : 3;      // persistent form where the K loop is short (tools/tune_conv.py)
-        return launch_conv3x3_wino(a, src, mh, s);
-    }
     a.wpk = packed + f.w[i];
-    return launch_conv3x3(a, src, -1, s);
+    switch (conv_form()) {
+        case FORM_WINO4: return launch_conv3x3_wino4(a, src, s);
+        case FORM_WINO2: {
+            int mh = wino_mh();
+            if (mh == 34) mh = a.cin <= 64 ? 4 : 3;      // persistent form where the K loop is short (tools/tune_conv.py)
+            return launch_conv3x3_wino(a, src, mh, s);
+        }
+        default: return launch_conv3x3(a, src, -1, s);
+    }
 }
 
 static int copy_bias(const float* src, float* dst, int n, hipStream_t s) {
@@ -138,9 +139,7 @@ int adain_encoder_pack(const float* const* w, const float* const* b, float* pack
     const Offsets f = enc_offsets();
     RET_IF(launch_pack_conv_first(w[0], b[0], w[1], b[1], packed, packed + f.first_b, s));
     for (int i = 0; i < 8; ++i) {
-        RET_IF(launch_pack_conv3x3(w[i + 2], packed + f.w[i], ENC[i].cin, ENC[i].cout, s));
-        RET_IF(launch_pack_wino(w[i + 2], packed + f.ww[i], ENC[i].cin, ENC[i].cout, s));
-        RET_IF(launch_pack_wino4(w[i + 2], packed + f.w4[i], ENC[i].cin, ENC[i].cout, s));
+        RET_IF(pack_layer(w[i + 2], packed + f.w[i], ENC[i].cin, ENC[i].cout, s));
         RET_IF(copy_bias(b[i + 2], packed + f.b[i], ENC[i].cout, s));
     }
     return 0;
@@ -151,9 +150,7 @@ int adain_decoder_pack(const float* const* w, const float* const* b, float* pack
     hipStream_t s = (hipStream_t)stream;
     const Offsets f = dec_offsets();
     for (int i = 0; i < 8; ++i) {
-        RET_IF(launch_pack_conv3x3(w[i], packed + f.w[i], DEC[i].cin, DEC[i].cout, s));
-        RET_IF(launch_pack_wino(w[i], packed + f.ww[i], DEC[i].cin, DEC[i].cout, s));
-        RET_IF(launch_pack_wino4(w[i], packed + f.w4[i], DEC[i].cin, DEC[i].cout, s));
+        RET_IF(pack_layer(w[i], packed + f.w[i], DEC[i].cin, DEC[i].cout, s));
         RET_IF(copy_bias(b[i], packed + f.b[i], DEC[i].cout, s));
     }
     RET_IF(launch_pack_conv_last(w[8], packed + f.last_w, s));
@@ -227,7 +224,7 @@ int adain_encode_multi(int count, const float* const* images, float* const* feat
         ch[i] = h[i]; cw[i] = w[i];
     }
     record(ev, 1, s);
-    const bool wino4 = use_winograd() && wino_mh() == 5;
+    const bool wino4 = conv_form() == FORM_WINO4;
     for (int l = 0; l < 8; ++l) {
         ConvArgs a{};
         a.cin = ENC[l].cin; a.cout = ENC[l].cout;
@@ -241,7 +238,7 @@ int adain_encode_multi(int count, const float* const* images, float* const* feat
         if (wino4) {
             // one launch for every batch: the persistent kernel's tile list runs over all of them (csrc/conv_wino4.hip, SEGMENTS)
             a.bias = packed + f.b[l];
-            a.wpk = packed + f.w4[l];
+            a.wpk = packed + f.w[l];
             RET_IF(launch_conv3x3_wino4_multi(a, segs, count, ENC[l].src, s));
         } else {
             for (int i = 0; i < count; ++i) {
@@ -376,9 +373,11 @@ int adain_conv3x3_pack(const float* w, float* packed, int cin, int cout, adain_s
     return launch_pack_conv3x3(w, packed, cin, cout, (hipStream_t)stream);
 }
 
-static unsigned long long* g_conv_dbg = nullptr;
-/* not part of the public ABI: tools/clock_probe.py sets a device buffer for the diagnostic variant 10 */
+static unsigned long long* g_conv_dbg = nullptr;     // stamp buffer of the diagnostic kernels; always null in the product library
+#ifdef ADAIN_DIAG
+/* diagnostic library only (libadain_hip_diag.so, tools/): a device buffer for the stamp / timing-only kernel variants */
 int adain_debug_set_conv_stamp_buffer(void* p) { g_conv_dbg = (unsigned long long*)p; return 0; }
+#endif
 
 int adain_conv3x3(const float* in, float* out, const float* packed_w, const float* bias, int n, int h, int w, int hs, int ws,
                   int cin, int cout, int src_mode, int relu, int pool_out, int variant, adain_stream_t stream) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace adain {
 
@@ -44,6 +45,18 @@ struct ConvSegs {
     int count, pad_;
     ConvSeg s[MAX_CONV_SEGS];
 };
+
+// Tuning and diagnostic switches exist only in the diagnostic build (-DADAIN_DIAG: libadain_hip_diag.so, loaded by tools/
+// through ADAIN_HIP_LIB): the product library takes no behaviour from the environment and holds no timing-only kernels.
+inline int tune_env(const char* name, int dflt) {
+#ifdef ADAIN_DIAG
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 // thread-local error text for adain_last_error()
 void set_error(const char* fmt, ...);

@@ -891,7 +891,9 @@ static int launch_variant(const ConvArgs& a, int variant, hipStream_t s) {
             break;
         case 7:   // 8 rows x 64 ch, 8 waves (4x2) of 2 rows x 32 ch: best pool-out form at cout = 64 (conv1_2: 139 vs 135 TF/s)
             return launch_cfg<MODE, 4, 2, 2, 1, 0, 5, 0>(a, s);
+#ifdef ADAIN_DIAG
         case 10: return launch_cfg<MODE, 4, 1, 2, 2, 0, 2, 2>(a, s);
+#endif
     }
     set_error("conv3x3: unknown tile variant %d", variant);
     return -1;
@@ -917,7 +919,7 @@ int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s) 
     }
     if (variant < 0) variant = conv3x3_auto_variant(a, src_mode);
     ConvArgs b = a;
-    static const int xcd_env = getenv("ADAIN_XCD_ORDER") ? atoi(getenv("ADAIN_XCD_ORDER")) : 1;
+    static const int xcd_env = tune_env("ADAIN_XCD_ORDER", 1);
     b.xcd_order = xcd_env;
     switch (src_mode) {
         case SRC_DIRECT:
@@ -952,7 +954,7 @@ int launch_conv_last(const float* in, float* out, const float* packed, const flo
     if ((long long)tx * ty * n > 0x7fffffffLL) { set_error("conv_last: bad grid"); return -1; }
     // single-buffered: 78 us vs 107 us double-buffered at 1024x1024 (occupancy beats overlap for this HBM-bound kernel);
     // ADAIN_LAST_ROWS = output rows per thread (1: 8-row tiles, 2: 16-row tiles)
-    static const int rows_env = getenv("ADAIN_LAST_ROWS") ? atoi(getenv("ADAIN_LAST_ROWS")) : 2;
+    static const int rows_env = tune_env("ADAIN_LAST_ROWS", 1);      // 16-row tiles measured slower (98 vs 80 us at 1024x1024: one workgroup fewer per CU)
     if (rows_env == 2 && H > 8) {
         const int ty2 = (H + 15) / 16;
         hipLaunchKernelGGL((conv_last_kernel<false, 2>), dim3((unsigned)(tx * ty2 * n)), dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty2);

@@ -643,16 +643,20 @@ int launch_conv3x3_wino(const ConvArgs& a0, int src_mode, int mh, hipStream_t s)
     a.tiles_y = (a.H + 4 * geo - 1) / (4 * geo);
     const long long blocks = (long long)a.tiles_x * a.tiles_y * (a.cout / 64) * a.n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv3x3_wino: bad grid %lld", blocks); return -1; }
-    static const int xcd_env = getenv("ADAIN_XCD_ORDER") ? atoi(getenv("ADAIN_XCD_ORDER")) : 1;
+    static const int xcd_env = tune_env("ADAIN_XCD_ORDER", 1);
     a.xcd_order = xcd_env;
     const dim3 g((unsigned)blocks);
     const bool up = src_mode == SRC_UP2X;
-    if (mh >= 13 && mh <= 16 && a.cin % 16 == 0 && !up) {      // diagnostic builds (tools/wino_probe.py)
+#ifdef ADAIN_DIAG
+    if (mh >= 13 && mh <= 16 && a.cin % 16 == 0 && !up) {      // stamp builds (tools/wino_probe.py), diagnostic library only
         if (mh == 13) hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT, true, 1>), g, dim3(256), 0, s, a);
         else if (mh == 14) hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT, true, 2>), g, dim3(256), 0, s, a);
         else if (mh == 15) hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT, true, 3>), g, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT, true, 4>), g, dim3(256), 0, s, a);
-    } else if (mh == 3 && a.cin % 16 == 0) {
+        return check_launch("conv3x3_wino(diag)");
+    }
+#endif
+    if (mh == 3 && a.cin % 16 == 0) {
         if (up) hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_UP2X>), g, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv3x3_wino2_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a);
     } else if (mh == 2) {

@@ -448,17 +448,22 @@ int launch_conv3x3_wino3(const ConvArgs& a0, int src_mode, hipStream_t s) {
     const int cus = device_cu_count();
     if (cus <= 0) { set_error("conv3x3_wino3: device query failed"); return -1; }
     long long grid = 2LL * cus;                          // two workgroups per CU (launch bounds), a multiple of the 8 XCDs
-    static const int grid_env = getenv("ADAIN_W3_GRID") ? atoi(getenv("ADAIN_W3_GRID")) : 0;       // debugging aid
+    static const int grid_env = tune_env("ADAIN_W3_GRID", 0);       // debugging aid
     if (grid_env > 0) grid = grid_env;
     grid -= grid % 8;
     if (grid < 8) grid = 8;
     const long long need = ((items + 7) / 8) * 8;        // never more workgroups than tiles (rounded up to the XCD count)
     if (grid > need) grid = need;
     const bool up = src_mode == SRC_UP2X;
-    static const int prio_env = getenv("ADAIN_W3_PRIO") ? atoi(getenv("ADAIN_W3_PRIO")) : 1;
+    static const int prio_env = tune_env("ADAIN_W3_PRIO", 1);
     const int prio = prio_env && grid == 2LL * cus;      // alternate wave priority only when every CU really holds two workgroups
-    if (a.dbg && !up) hipLaunchKernelGGL((conv3x3_wino3_kernel<SRC_DIRECT, true>), dim3((unsigned)grid), dim3(256), 0, s, a, (int)items, prio);
-    else if (up) hipLaunchKernelGGL((conv3x3_wino3_kernel<SRC_UP2X>), dim3((unsigned)grid), dim3(256), 0, s, a, (int)items, prio);
+#ifdef ADAIN_DIAG
+    if (a.dbg && !up) {
+        hipLaunchKernelGGL((conv3x3_wino3_kernel<SRC_DIRECT, true>), dim3((unsigned)grid), dim3(256), 0, s, a, (int)items, prio);
+        return check_launch("conv3x3_wino3(diag)");
+    }
+#endif
+    if (up) hipLaunchKernelGGL((conv3x3_wino3_kernel<SRC_UP2X>), dim3((unsigned)grid), dim3(256), 0, s, a, (int)items, prio);
     else hipLaunchKernelGGL((conv3x3_wino3_kernel<SRC_DIRECT>), dim3((unsigned)grid), dim3(256), 0, s, a, (int)items, prio);
     return check_launch("conv3x3_wino3");
 }

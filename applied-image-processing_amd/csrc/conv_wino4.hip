@@ -557,13 +557,13 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     a.tiles_y = (a.H + 7) / 8;
     const long long blocks = (long long)a.tiles_x * a.tiles_y * (a.cout / 32) * a.n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv3x3_wino4: bad grid %lld", blocks); return -1; }
-    static const int order_env = getenv("ADAIN_W4_ORDER") ? atoi(getenv("ADAIN_W4_ORDER")) : 1;
+    static const int order_env = tune_env("ADAIN_W4_ORDER", 1);
     a.xcd_order = order_env;
     const dim3 g((unsigned)blocks);
     // persistent form (default) whenever the launch has at least two tiles per resident workgroup; ADAIN_W4_PERSIST = largest
     // cin it is used for (0 = never: one tile per workgroup).  +2-3 % on most layer shapes, +1.1 % on the config-2 step.
-    static const int persist_env = getenv("ADAIN_W4_PERSIST") ? atoi(getenv("ADAIN_W4_PERSIST")) : 1 << 20;
-    static const int prio_env = getenv("ADAIN_W4_PRIO") ? atoi(getenv("ADAIN_W4_PRIO")) : 1;
+    static const int persist_env = tune_env("ADAIN_W4_PERSIST", 1 << 20);
+    static const int prio_env = tune_env("ADAIN_W4_PRIO", 1);
     const long long pgrid = persistent_grid();
     if (pgrid <= 0) { set_error("conv3x3_wino4: device query failed"); return -1; }
     const bool persist = !a.dbg && a.cin <= persist_env && a.cin >= 2 * W4_KR && pgrid >= 8 && blocks >= 2 * pgrid;
@@ -580,7 +580,7 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
 #ifdef ADAIN_DIAG
     // timing / stamp builds of the one-tile form (tools/ only: libadain_hip_diag.so); selected by ADAIN_W4_DIAG when a stamp
     // buffer is set
-    static const int diag_env = getenv("ADAIN_W4_DIAG") ? atoi(getenv("ADAIN_W4_DIAG")) : 0;
+    static const int diag_env = tune_env("ADAIN_W4_DIAG", 0);
     if (a.dbg && src_mode == SRC_DIRECT) {
         switch (diag_env) {
 #define W4_DIAG_CASE(D) case D: hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, D>), g, dim3(256), 0, s, a, m, items, 0); break;
@@ -615,8 +615,8 @@ int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int c
         total += (long long)m.s[i].tiles_x * m.s[i].tiles_y * (a.cout / 32) * a.n;
         if (total > 0x7fffffffLL) { set_error("conv3x3_wino4_multi: too many tiles"); return -1; }
     }
-    static const int merge_env = getenv("ADAIN_W4_MERGE") ? atoi(getenv("ADAIN_W4_MERGE")) : 1;
-    static const int prio_env = getenv("ADAIN_W4_PRIO") ? atoi(getenv("ADAIN_W4_PRIO")) : 1;
+    static const int merge_env = tune_env("ADAIN_W4_MERGE", 1);
+    static const int prio_env = tune_env("ADAIN_W4_PRIO", 1);
     const long long pgrid = persistent_grid();
     if (pgrid <= 0) { set_error("conv3x3_wino4: device query failed"); return -1; }
     if (count == 1 || !merge_env || a.cin < 2 * W4_KR || pgrid < 8 || total < 2 * pgrid) {

@@ -12,7 +12,8 @@ import threading
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libadain_hip.so")
+# ADAIN_HIP_LIB selects another build of the same ABI (tools/ point it at libadain_hip_diag.so, build.py --diag)
+LIB_PATH = os.environ.get("ADAIN_HIP_LIB") or os.path.join(_PKG, "libadain_hip.so")
 
 SRC_DIRECT, SRC_UP2X, SRC_POOL2 = 0, 1, 2
 

@@ -51,8 +51,11 @@ import applied_image_processing_amd.synth as synth
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0           # same guide: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable by a float4 copy)
-WINOGRAD = os.environ.get("ADAIN_WINOGRAD", "1") != "0"      # the C library's default; ADAIN_WINOGRAD=0 = direct implicit GEMM
-WINO_FORM = int(os.environ.get("ADAIN_WINO_MH", "5"))          # the C library's default: 5 = F(4,3) x F(2,3); others F(2x2,3x3)
+# The product library always runs the F(4,3) x F(2,3) kernels; only the diagnostic build (ADAIN_HIP_LIB=libadain_hip_diag.so)
+# reads ADAIN_WINOGRAD=0 (direct implicit GEMM) / ADAIN_WINO_MH (F(2x2,3x3) forms) for A/B runs.
+_DIAG_LIB = "diag" in os.path.basename(rt.LIB_PATH)
+WINOGRAD = not _DIAG_LIB or os.environ.get("ADAIN_WINOGRAD", "1") != "0"
+WINO_FORM = int(os.environ.get("ADAIN_WINO_MH", "5")) if _DIAG_LIB else 5
 # multiplies the conv3x3 kernel executes on the matrix pipe per direct-convolution multiply
 EXECUTED = (24.0 / 72.0 if WINO_FORM == 5 else 16.0 / 36.0) if WINOGRAD else 1.0
 CONV_KERNEL = ("conv3x3_mfma_kernel / conv3x3_persist_kernel" if not WINOGRAD else

@@ -4,6 +4,11 @@ ADAIN_W4_DIAG=<n> ADAIN_W4_PERSIST=0 python tools/probes/diag_ab.py   (the stamp
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "../.."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + "/..")
+import _diag  # noqa: F401,E402  (selects libadain_hip_diag.so)
 import applied_image_processing_amd.runtime as rt
 import applied_image_processing_amd.synth as synth
 dev = torch.device("cuda", 0)

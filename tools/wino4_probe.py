@@ -10,6 +10,9 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag  # noqa: F401,E402  (selects libadain_hip_diag.so)
 import applied_image_processing_amd.runtime as rt
 import applied_image_processing_amd.synth as synth
 
