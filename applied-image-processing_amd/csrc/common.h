@@ -42,7 +42,8 @@ struct ConvSeg {
 };
 constexpr int MAX_CONV_SEGS = 4;
 struct ConvSegs {
-    int count, pad_;
+    int count;
+    int ctg;            // channel tiles per group of the persistent walk (divides cout / 32): see conv3x3_wino4_kernel
     ConvSeg s[MAX_CONV_SEGS];
 };
 

@@ -144,7 +144,24 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     } else if (a.xcd_order && (gridDim.x & 7) == 0) {
         lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
     }
-    if (!PERSIST && a.xcd_order == 2) {          // pixel tile fastest: the workgroups resident on an XCD share one or two channel tiles' weights
+    // Persistent walk: inside a segment the items are ordered (channel-tile GROUP, image, pixel tile, channel tile in the group),
+    // group size m.ctg.  With ctg == nct (every channel tile in one group) consecutive items are the channel tiles of one pixel
+    // tile: the 64 workgroups resident on an XCD share halos, but a layer whose transformed weights exceed the XCD's 4 MB L2
+    // (256 -> 256: 6.3 MB) re-fetches them from the Infinity Cache once per group of 8 pixel tiles.  With a smaller group an
+    // XCD's contiguous range stays inside ONE group for many pixel tiles: its weights (cin * 32 ctg * 96 B) stay in L2 and
+    // the halos are fetched once per group instead.
+    auto decode = [&](int li, int ntl, int nimgs, int& ct_, int& pt_, int& img_) {
+        const int G = m.ctg;
+        const int c = li % G, r = li / G;
+        const int per = ntl * nimgs;
+        const int g = r / per, pi = r - g * per;
+        ct_ = g * G + c;
+        img_ = pi / ntl;
+        pt_ = pi - img_ * ntl;
+    };
+    if constexpr (PERSIST) {
+        decode(lid, tiles, m.s[seg].n, ct, pt, img);
+    } else if (a.xcd_order == 2) {          // pixel tile fastest: the workgroups resident on an XCD share one or two channel tiles' weights
         pt = lid % tiles; lid /= tiles;
         ct = lid % nct;
         img = lid / nct;
@@ -443,7 +460,8 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 const int nitem = item + stride < hi ? item + stride : item;
                 const int nseg = seg_of(nitem);
                 const int nli = nitem - m.s[nseg].item0, ngtx = m.s[nseg].tiles_x, ntiles = ngtx * m.s[nseg].tiles_y;
-                const int nct_ = nli % nct, nr = nli / nct, npt = nr % ntiles, nimg = nr / ntiles;
+                int nct_, npt, nimg;
+                decode(nli, ntiles, m.s[nseg].n, nct_, npt, nimg);
                 const int ntx0 = (npt % ngtx) * 32, nty0 = (npt / ngtx) * 8;
                 const int wso_next = ((nct_ * 4 + wj) * nch) * 6144;
                 if (prio_mode) {
@@ -543,6 +561,21 @@ static int check_wino4_shape(const ConvArgs& a, int src_mode) {
     return 0;
 }
 
+// Channel tiles per group of the persistent walk: the largest divisor of cout / 32 whose transformed weights (cin x 32 G x 24
+// floats) fit W4_L2_WEIGHT_BYTES of an XCD's 4 MB L2 (the rest is left to the halos and outputs streaming through).
+constexpr size_t W4_L2_WEIGHT_BYTES = 3u << 20;
+static int walk_group(int cin, int cout) {
+    const int nct = cout / 32;
+    static const int force = tune_env("ADAIN_W4_CTG", 0);       // diagnostic build: 0 = automatic, -1 = all channel tiles, > 0 = that many
+    if (force < 0) return nct;
+    int g = nct;
+    if (force > 0) g = force < nct ? force : nct;
+    else
+        while (g > 1 && (size_t)cin * 32 * g * 96 > W4_L2_WEIGHT_BYTES) --g;
+    while (nct % g) --g;
+    return g;
+}
+
 static long long persistent_grid() {
     const int cus = device_cu_count();
     if (cus <= 0) return 0;
@@ -570,6 +603,7 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     const int items = (int)blocks;
     ConvSegs m{};
     m.count = 1;
+    m.ctg = walk_group(a.cin, a.cout);
     m.s[0] = ConvSeg{a.in, a.out, a.n, a.H, a.W, a.Hs, a.Ws, a.tiles_x, a.tiles_y, 0};
     if (persist) {
         const dim3 pg((unsigned)pgrid);
@@ -601,6 +635,7 @@ int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int c
     if (count < 1 || count > MAX_CONV_SEGS) { set_error("conv3x3_wino4_multi: 1..%d segments, got %d", MAX_CONV_SEGS, count); return -1; }
     ConvSegs m{};
     m.count = count;
+    m.ctg = walk_group(layer.cin, layer.cout);
     long long total = 0;
     ConvArgs a = layer;
     for (int i = 0; i < count; ++i) {

@@ -507,6 +507,12 @@ def main():
         while pending:
             gathered[0] = pending.pop(0)()
 
+    if use_dist:
+        # connection setup of the device transport (RCCL builds its communicator on first use) stays out of every timed region,
+        # whatever --warmup is
+        probe = torch.zeros((args.batch, 8, 8, 3), dtype=torch.uint8, device=device)
+        sh.gather_frames(probe if transport == "rccl" else probe.cpu(), n_job, dst=0)
+        barrier()
     for _ in range(args.warmup):
         out = one_step()
     drain()
