@@ -53,7 +53,7 @@ def main(d):
                 print(f"| `{k}` | {c} | {a[0]} | {a[1] / a[0]:.4g} | {a[1]:.6g} |")
 
 
-def traffic(fetch_dir, write_dir, key, out_json):
+def traffic(fetch_dir, write_dir, key, out_json, source=""):
     """HBM bytes per conv3x3 launch = 2 * FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads,
     MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KB per dispatch, from two separate --pmc passes."""
     import json
@@ -76,13 +76,16 @@ def traffic(fetch_dir, write_dir, key, out_json):
         d = {}
     d[key] = {"hbm_bytes_per_conv3x3_launch": round(per_launch), "fetch_kb_per_launch_raw": round(f / nf, 1),
               "write_kb_per_launch": round(w / nw, 1), "dispatches": nf,
-              "note": "2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, averaged over every conv3x3_* (wino2 / mfma / persist) dispatch of bench.py"}
+              "source": source,
+              "note": "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads), two separate "
+                      "rocprofv3 --pmc passes of the bench command, averaged over every conv3x3_* dispatch; FETCH_SIZE counts L2 misses, "
+                      "including those the Infinity Cache serves"}
     json.dump(d, open(out_json, "w"), indent=1, sort_keys=True)
     print(json.dumps(d[key]))
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "--traffic":
-        traffic(*sys.argv[2:6])
+        traffic(*sys.argv[2:7])
     else:
         main(sys.argv[1])
