@@ -41,7 +41,7 @@ def build(force=False, verbose=False, diag=False):
     objdir = os.path.join(PKG, "build_diag" if diag else "build")
     os.makedirs(objdir, exist_ok=True)
     lib = DIAG_LIB if diag else LIB
-    flags = FLAGS + (["-DADAIN_DIAG"] if diag else [])
+    flags = FLAGS + (["-DADAIN_DIAG"] if diag else []) + os.environ.get("ADAIN_EXTRA_HIPCC_FLAGS", "").split()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_utils.h"), os.path.join(INC, "adain_hip.h")]
     hipcc = _hipcc()
     jobs = []

@@ -44,6 +44,8 @@ constexpr int MAX_CONV_SEGS = 4;
 struct ConvSegs {
     int count;
     int ctg;            // channel tiles per group of the persistent walk (divides cout / 32): see conv3x3_wino4_kernel
+    int stagger;        // start delay of the second half of the persistent grid in units of 64 cycles
+    int pad_;
     ConvSeg s[MAX_CONV_SEGS];
 };
 

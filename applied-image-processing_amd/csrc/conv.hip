@@ -635,10 +635,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_persist_kernel(ConvAr
 //     accumulator layout itself would need 64 dword stores.
 // ---------------------------------------------------------------------------------------------
 constexpr int CF_OSTR = 68;      // floats per pixel of the row buffer: b128 writes of 8 consecutive pixels cover all 32 banks
-__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ img_nchw,
-                                                         float* __restrict__ out, const float* __restrict__ wpk,
-                                                         const float* __restrict__ bias, int H, int W, int tiles_x,
-                                                         int tiles_y) {
+// Persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ...; the NEXT tile's halo pixels (at most 2 per thread) are loaded
+// into registers before the current tile's MFMAs and stores, so a workgroup's memory latency overlaps its own matrix work
+// (one tile per workgroup ran load -> 80 MFMAs per wave -> store strictly in sequence: 3.2 TB/s).
+__global__ __launch_bounds__(256, 2) void conv_first_kernel(const float* __restrict__ img_nchw,
+                                                            float* __restrict__ out, const float* __restrict__ wpk,
+                                                            const float* __restrict__ bias, int H, int W, int tiles_x,
+                                                            int tiles_y, int ntiles) {
     constexpr int HALO = 10 * 34;
     // the halo image (5.4 KiB) and the four waves' row buffers (4 x 8.5 KiB) share the allocation: 34 KiB, 4 workgroups per CU
     __shared__ __attribute__((aligned(16))) float smem[4 * 32 * CF_OSTR];
@@ -648,73 +651,95 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int tiles = tiles_x * tiles_y;
-    const int pt = blockIdx.x % tiles;
-    const int img = blockIdx.x / tiles;
-    const int tx0 = (pt % tiles_x) * 32, ty0 = (pt / tiles_x) * 8;
-    const float* __restrict__ src = img_nchw + (size_t)img * 3 * H * W;
     const size_t plane = (size_t)H * W;
+    const bool second = tid + 256 < HALO;          // threads 0..83 own a second halo pixel
 
-    for (int p = tid; p < HALO; p += 256) {
-        const int hy = p / 34, hx = p - hy * 34;
-        const int y = reflect1(ty0 + hy - 1, H), x = reflect1(tx0 + hx - 1, W);
-        const float* __restrict__ q = src + (size_t)y * W + x;
-        *(f32x4*)(smem + p * 4) = f32x4{q[0], q[plane], q[2 * plane], 0.f};
-    }
-    __syncthreads();
-
-    f32x16 acc[2][2];      // [channel tile][row of this wave]
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
-
-#pragma unroll
-    for (int g = 0; g < 5; ++g) {
-        const int tap = min(2 * g + lh, 8);          // the tenth tap carries zero weights: any halo pixel will do
-        const int ty = tap / 3, tx = tap - ty * 3;
-        f32x4 wf[2], xf[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) wf[t] = *(const f32x4*)(wpk + ((t * 5 + g) * 64 + lane) * 4);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) xf[m] = *(const f32x4*)(smem + ((wave * 2 + m + ty) * 34 + li + tx) * 4);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[t][s], xf[m][s], acc[t][m], 0, 0, 0);
-    }
-    __syncthreads();                                 // every wave has read its halo pixels: the row buffers may overwrite them
-
-    float* const st = smem + wave * (32 * CF_OSTR);
-    const rsrc_t dst = make_rsrc(out + (size_t)img * H * W * 64, (unsigned)((size_t)H * W * 256));
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int y = ty0 + wave * 2 + m;
-        // lane (li, lh) holds channels 32 t + 8 q + 4 lh + (0..3) of pixel li in acc[t][m][4 q .. 4 q + 3]
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ch = 32 * t + 8 * q + 4 * lh;
-                const f32x4 b4 = *(const f32x4*)(bias + ch);
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[t][m][4 * q + e] + b4[e], 0.f);
-                *(f32x4*)(st + li * CF_OSTR + ch) = v;
-            }
-        // the row buffer is private to the wave and LDS operations of one wave complete in order: no barrier
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int idx = k * 64 + lane, px = idx >> 4, q16 = idx & 15;
-            const f32x4 v = *(const f32x4*)(st + px * CF_OSTR + q16 * 4);
-            const int x = tx0 + px;
-            const int off = ((y * W + x) * 64 + q16 * 4) * 4;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, (y < H && x < W) ? off : 0x7fffffff, 0, 0);
+    // halo pixels p = tid and tid + 256 of tile t -> registers
+    f32x4 h0, h1;
+    auto halo_load = [&](int t) {
+        const int pt = t % tiles, img = t / tiles;
+        const int tx0 = (pt % tiles_x) * 32, ty0 = (pt / tiles_x) * 8;
+        const float* __restrict__ src = img_nchw + (size_t)img * 3 * plane;
+        {
+            const int hy = tid / 34, hx = tid - hy * 34;
+            const float* __restrict__ q = src + (size_t)reflect1(ty0 + hy - 1, H) * W + reflect1(tx0 + hx - 1, W);
+            h0 = f32x4{q[0], q[plane], q[2 * plane], 0.f};
         }
+        if (second) {
+            const int p = tid + 256, hy = p / 34, hx = p - hy * 34;
+            const float* __restrict__ q = src + (size_t)reflect1(ty0 + hy - 1, H) * W + reflect1(tx0 + hx - 1, W);
+            h1 = f32x4{q[0], q[plane], q[2 * plane], 0.f};
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    halo_load(t);
+    for (;;) {
+        const int pt = t % tiles, img = t / tiles;
+        const int tx0 = (pt % tiles_x) * 32, ty0 = (pt / tiles_x) * 8;
+        *(f32x4*)(smem + tid * 4) = h0;
+        if (second) *(f32x4*)(smem + (tid + 256) * 4) = h1;
+        __syncthreads();
+        const int tn = t + gridDim.x;
+        if (tn < ntiles) halo_load(tn);                  // in flight during this tile's MFMAs and stores
+
+        f32x16 acc[2][2];      // [channel tile][row of this wave]
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][m][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {
+            const int tap = min(2 * g + lh, 8);          // the tenth tap carries zero weights: any halo pixel will do
+            const int ty = tap / 3, tx = tap - ty * 3;
+            f32x4 wf[2], xf[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) wf[c] = *(const f32x4*)(wpk + ((c * 5 + g) * 64 + lane) * 4);      // 10 KiB in all: L1-resident
+#pragma unroll
+            for (int m = 0; m < 2; ++m) xf[m] = *(const f32x4*)(smem + ((wave * 2 + m + ty) * 34 + li + tx) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[c][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[c][s], xf[m][s], acc[c][m], 0, 0, 0);
+        }
+        __syncthreads();                                 // every wave has read its halo pixels: the row buffers may overwrite them
+
+        float* const st = smem + wave * (32 * CF_OSTR);
+        const rsrc_t dst = make_rsrc(out + (size_t)img * H * W * 64, (unsigned)((size_t)H * W * 256));
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int y = ty0 + wave * 2 + m;
+            // lane (li, lh) holds channels 32 c + 8 q + 4 lh + (0..3) of pixel li in acc[c][m][4 q .. 4 q + 3]
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = 32 * c + 8 * q + 4 * lh;
+                    const f32x4 b4 = *(const f32x4*)(bias + ch);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[c][m][4 * q + e] + b4[e], 0.f);
+                    *(f32x4*)(st + li * CF_OSTR + ch) = v;
+                }
+            // the row buffer is private to the wave and LDS operations of one wave complete in order: no barrier
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = k * 64 + lane, px = idx >> 4, q16 = idx & 15;
+                const f32x4 v = *(const f32x4*)(st + px * CF_OSTR + q16 * 4);
+                const int x = tx0 + px;
+                const int off = ((y * W + x) * 64 + q16 * 4) * 4;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, (y < H && x < W) ? off : 0x7fffffff, 0, 0);
+            }
+        }
+        if (tn >= ntiles) break;
+        t = tn;
+        __syncthreads();                                 // the row buffers have been read: the next halo may overwrite them
     }
 }
 
@@ -941,8 +966,12 @@ int launch_conv_first(const float* img, float* out, const float* packed, const f
     if (H < 2 || W < 2 || n < 1) { set_error("conv_first: H, W must be >= 2, got %dx%d", H, W); return -1; }
     if ((size_t)H * W * 256 >= 0x7fffffffULL) { set_error("conv_first: a 64-channel image of %dx%d reaches 2 GiB (32-bit buffer offsets)", H, W); return -1; }
     const int tx = (W + 31) / 32, ty = (H + 7) / 8;
-    if ((long long)tx * ty * n > 0x7fffffffLL) { set_error("conv_first: bad grid"); return -1; }
-    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(tx * ty * n)), dim3(256), 0, s, img, out, packed, bias, H, W, tx, ty);
+    const long long ntiles = (long long)tx * ty * n;
+    if (ntiles > 0x7fffffffLL) { set_error("conv_first: bad grid"); return -1; }
+    const int cus = device_cu_count();
+    if (cus <= 0) { set_error("conv_first: device query failed"); return -1; }
+    const long long grid = ntiles < 2LL * cus ? ntiles : 2LL * cus;        // 2 workgroups per CU walk the tiles
+    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)grid), dim3(256), 0, s, img, out, packed, bias, H, W, tx, ty, (int)ntiles);
     return check_launch("conv_first");
 }
 

@@ -34,12 +34,25 @@ namespace adain {
 
 namespace {
 constexpr int W4_KR = 16;                    // channels per raw stage = 2 chunks of 8
-constexpr int W4_RSTR = W4_KR + 4;           // floats per halo pixel (80 B)
+constexpr int W4_RSTR = W4_KR + 4;           // floats per halo pixel (80 B = 5 quads: an odd number of 16-byte bank quads)
 constexpr int W4_HALO_W = 34, W4_HALO_H = 10;
 constexpr int W4_HALO = W4_HALO_H * W4_HALO_W;        // 340 pixels
 constexpr int W4_RITEMS = 6;                           // 340 x 4 quads over 256 threads
-constexpr int W4_RBUF = W4_RITEMS * 64 * W4_RSTR;      // rounded up to the staging items: 384 pixels
+// LDS image of the raw halo, DE-INTERLEAVED by column parity: plane E holds the even halo columns, plane O the odd ones, each
+// [10 rows][17 columns] pixels of 20 floats.  The tiles of a workgroup sit 2 pixels apart, i.e. 1 plane pixel = 5 quads: the 16
+// lanes that one LDS cycle of a ds_read_b128 serves ({0-3,12-15,20-27} ..., MI355X_MICROARCH.md, LDS) then read 16 different
+// quads of the 64 banks.  In one interleaved image (round 1: [10][34] pixels) neighbouring tiles are 10 quads apart and every
+// patch read was a two-way bank conflict (SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE).  Row stride 88 quads (17 x 5 + 3):
+// the second tile row, 4 halo rows down, lands on the same quads modulo 16 as the first, so the columns 4-11 of one row and
+// 0-3 / 12-15 of the other (the hardware's lane groups) still cover all 16.  Plane O starts 4 quads (mod 8) after plane E: the
+// two neighbouring pixels that one 8-lane group of a staging ds_write_b128 stores cover all 32 banks.
+constexpr int W4_PROW = 17 * W4_RSTR + 12;             // 352 floats per plane row
+constexpr int W4_PLANE = W4_HALO_H * W4_PROW + 16;     // 3536 floats per plane
+constexpr int W4_TAIL = 2 * W4_PLANE;                  // staging items past the halo (44 pixels) land here, never read
+constexpr int W4_RBUF = 8192;                          // 2 planes + tail = 7952 floats, rounded: two buffers = the exchange area
 constexpr int W4_PEX = 4 * 4 * 32 * 32;                // [column j][a][tile][32 channels] floats = 64 KiB
+static_assert(W4_TAIL + (W4_RITEMS * 64 - W4_HALO) * W4_RSTR <= W4_RBUF, "LDS layout");
+static_assert(W4_PROW % 16 == 0 && (W4_PROW / 4) % 4 == 0 && (W4_PLANE / 4) % 8 == 4, "bank layout");
 static_assert(W4_HALO * 4 <= W4_RITEMS * 256, "staging items");
 static_assert(2 * W4_RBUF <= W4_PEX, "LDS layout");
 
@@ -84,7 +97,8 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
 //   per CU, 256->256 at 256^2 / 64->64 at 1024^2): 5 = no input transform at all (+16 %), 6 = no patch reads, arithmetic on stale
 //   registers (+16 %: the LDS reads are the transform's whole cost), 9 = ds_read_b32 instead of b128 (+5 %), 7 = no stage
 //   barrier (+2 %), 8 = no halo loads or stores (+8 / +10 %), 10 = no halo loads (+5 / +8 %), 11 = no halo stores (+3 %),
-//   12 = (correct results) 12-slot weight ring, a whole chunk ahead (+1 %); a build that sent the halo straight to LDS
+//   12 = (correct results) 12-slot weight ring, a whole chunk ahead (+1 %); 13 = no weight loads in the main loop, 14 = no vector-memory
+//   loads at all in the main loop (round 2: prices the CU's vector-memory path); a build that sent the halo straight to LDS
 //   (`buffer_load ... lds`, wrong image layout, no staging registers or ds_writes; since removed) measured +3 %.  In a bare MFMA loop neither LDS reads nor streaming
 //   weight loads cost the matrix pipe anything (tools/probes/mfma_chain_probe.hip), so these are waits, not port conflicts.
 // PERSIST: a workgroup walks a list of tiles (grid = 2 per CU; XCD x owns a contiguous range of the tile list, channel tile
@@ -105,10 +119,16 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     unsigned* const steplog = (unsigned*)(smem + W4_PEX);     // DIAG 1, 2: [wave][96] low words of s_memtime
     int nlog = 0;
     unsigned long long phase[4] = {0, 0, 0, 0};
+    unsigned long long tpx[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // DIAG 4
     if constexpr (DIAG == 3) phase[0] = __builtin_amdgcn_s_memrealtime();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+#ifdef W4_AGPR_ACC
+    // an inline-asm AGPR operand makes the compiler select the MFMAs' AGPR-destination form: the 96 accumulator registers then
+    // live in the accumulator half of the register file (experiment: -DW4_AGPR_ACC)
+    { float agpr_hint = 1.0f; asm volatile("; agpr hint %0" ::"a"(agpr_hint)); }
+#endif
     const int wj = __builtin_amdgcn_readfirstlane(tid >> 6);      // transform column of this wave
     // the one lane constant kept live through the main loop; other lane-derived addresses are rebuilt from an opaque copy
     const int wvo = lane * 16;
@@ -201,11 +221,22 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
 #pragma unroll
         for (int k = 0; k < W4_RITEMS; ++k) rawreg[k] = buf_load4(src, roff[k], soff);
     };
-    auto raw_store = [&](float* buf) {
-        const int t = lane_now() | (wj << 6);
-        const int st_base = (t >> 2) * W4_RSTR + (t & 3) * 4;      // item k: pixel (t >> 2) + 64 k -> one address + immediates
+    // LDS address (in floats) of staging item k of this thread: pixel (t >> 2) + 64 k of the halo, quad t & 3; depends on the
+    // thread only, computed once
+    int sa[W4_RITEMS];
+    {
+        const int t = tid;
 #pragma unroll
-        for (int k = 0; k < W4_RITEMS; ++k) *(f32x4*)(buf + st_base + k * 64 * W4_RSTR) = rawreg[k];   // items past the halo: unused tail
+        for (int k = 0; k < W4_RITEMS; ++k) {
+            const int hp = (t >> 2) + 64 * k, q = t & 3;
+            const int hy = (hp * 241) >> 13, hx = hp - hy * W4_HALO_W;          // hp / 34 for hp < 400
+            sa[k] = hp < W4_HALO ? (hx & 1) * W4_PLANE + hy * W4_PROW + (hx >> 1) * W4_RSTR + q * 4
+                                 : W4_TAIL + (hp - W4_HALO) * W4_RSTR + q * 4;
+        }
+    }
+    auto raw_store = [&](float* buf) {
+#pragma unroll
+        for (int k = 0; k < W4_RITEMS; ++k) *(f32x4*)(buf + sa[k]) = rawreg[k];
     };
 
     // ---- weights: one b128 fragment per step (row position r), ring slot = r, loaded 5 steps ahead ---------------------------
@@ -250,6 +281,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         }
     }
     __syncthreads();
+    if constexpr (DIAG == 4) tpx[3] = __builtin_amdgcn_s_memtime();
     {
         const int le = lane_now(), q8 = le & 7, tt = le >> 3;
         const int tl = wj * 8 + tt;
@@ -270,6 +302,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         if constexpr (PERSIST) {
             __syncthreads();                               // every wave has its P values: the LDS image is free again
             raw_store(Rs);                                 // the next tile's first halo stage (loaded during this tile)
+            if constexpr (DIAG == 4) tpx[4] = __builtin_amdgcn_s_memtime();
         }
 #pragma unroll
         for (int ap = 0; ap < 4; ++ap) {
@@ -339,29 +372,27 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         int xaddr = 0;          // this lane's patch origin in the halo image (floats), rebuilt at the start of every chunk
         auto xf_addr = [&]() {
             const int l = lane_now(), li = l & 31, lh = l >> 5;
-            xaddr = ((4 * (li >> 4)) * W4_HALO_W + 2 * (li & 15)) * W4_RSTR + 4 * lh;
+            xaddr = (4 * (li >> 4)) * W4_PROW + (li & 15) * W4_RSTR + 4 * lh;
         };
+        // patch pixel (row a, column c of the 6 x 4 patch) relative to xaddr: plane c & 1, plane column + (c >> 1)
+        auto poff = [](int a, int c) { return (c & 1) * W4_PLANE + a * W4_PROW + (c >> 1) * W4_RSTR; };
         auto xf_read3 = [&](const float* rb, int a0) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                dA[k] = *(const f32x4*)(rb + xaddr + ((a0 + k) * W4_HALO_W + cA) * W4_RSTR);
-                dB[k] = *(const f32x4*)(rb + xaddr + ((a0 + k) * W4_HALO_W + cB) * W4_RSTR);
+                dA[k] = *(const f32x4*)(rb + xaddr + poff(a0 + k, cA));
+                dB[k] = *(const f32x4*)(rb + xaddr + poff(a0 + k, cB));
             }
         };
         // one patch read (read index i = 0..5 of rows a0..a0+2: i / 2 = row, i & 1 = column cA / cB)
         auto xf_read1 = [&](const float* rb, int a0, auto II) {
             constexpr int i = decltype(II)::value, k = i / 2;
             if constexpr (DIAG == 9) {      // timing-only: the same number of LDS instructions, a quarter of the bytes
-                if constexpr ((i & 1) == 0) dA[k][0] = *(const float*)(rb + xaddr + ((a0 + k) * W4_HALO_W + cA) * W4_RSTR);
-                else dB[k][0] = *(const float*)(rb + xaddr + ((a0 + k) * W4_HALO_W + cB) * W4_RSTR);
-            } else if constexpr ((i & 1) == 0) dA[k] = *(const f32x4*)(rb + xaddr + ((a0 + k) * W4_HALO_W + cA) * W4_RSTR);
-            else dB[k] = *(const f32x4*)(rb + xaddr + ((a0 + k) * W4_HALO_W + cB) * W4_RSTR);
+                if constexpr ((i & 1) == 0) dA[k][0] = *(const float*)(rb + xaddr + poff(a0 + k, cA));
+                else dB[k][0] = *(const float*)(rb + xaddr + poff(a0 + k, cB));
+            } else if constexpr ((i & 1) == 0) dA[k] = *(const f32x4*)(rb + xaddr + poff(a0 + k, cA));
+            else dB[k] = *(const f32x4*)(rb + xaddr + poff(a0 + k, cB));
         };
-        int saddr = 0;
-        auto st_addr = [&]() {
-            const int t = lane_now() | (wj << 6);
-            saddr = (t >> 2) * W4_RSTR + (t & 3) * 4;              // item k: pixel (t >> 2) + 64 k -> one address + immediates
-        };
+
         // One chunk of 8 channels = 24 MFMAs in 24 scheduling regions of ONE MFMA plus its share of the chunk's other work
         // (issued right behind it, in its 64-cycle shadow).  Regions alternate between the accumulators of row positions 2d
         // and 2d+1 (d = region / 8): four back-to-back MFMAs on one accumulator are a dependent chain (tools/wino4_probe.py:
@@ -381,7 +412,9 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 }
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[6 * par + r][sidx], aq[r][sidx], acc[r], 0, 0, 0);
                 // ---- weight ring: (this chunk) slots 4, 5 at mini-steps 0, 1; (next chunk) slots 0, 1 at 4, 5; slots 2, 3 at 8, 9 ----
-                if constexpr (RING12) {
+                if constexpr (DIAG == 13 || DIAG == 14) {
+                    // timing-only: no weight loads in the main loop (the ring keeps its first fragments)
+                } else if constexpr (RING12) {
                     if constexpr (b == 0 && m < 6) bq[6 * (1 - par) + m] = buf_load4(wsr, wvo, wnext + m * 1024);
                 } else if constexpr (b == 0) {
                     if constexpr (m == 0) bq[4] = buf_load4(wsr, wvo, wso + 4 * 1024);
@@ -392,7 +425,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                     if constexpr (m == 9) bq[3] = buf_load4(wsr, wvo, wnext + 3 * 1024);
                 }
                 // ---- halo loads two stages ahead, in the first two thirds of the chunk (regions 5, 7, 9, 11, 13, 15) ----
-                if constexpr (ld && DIAG != 10 && b == 1 && h >= 5 && h <= 15) {      // DIAG 10: timing-only, no halo loads (stale stores)
+                if constexpr (ld && DIAG != 10 && DIAG != 14 && b == 1 && h >= 5 && h <= 15) {      // DIAG 10: timing-only, no halo loads (stale stores)
                     constexpr int k = (h - 5) / 2;
                     rawreg[k] = buf_load4(src, roff[k], raw_soff);
                 }
@@ -412,8 +445,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 }
                 // ---- halo store of the stage loaded one stage ago ----
                 if constexpr (st && DIAG != 8 && DIAG != 11) {
-                    if constexpr (h == 16) st_addr();
-                    if constexpr (h >= 17 && h <= 22) *(f32x4*)(store_to + saddr + (h - 17) * 64 * W4_RSTR) = rawreg[h - 17];
+                    if constexpr (h >= 17 && h <= 22) *(f32x4*)(store_to + sa[h - 17]) = rawreg[h - 17];
                 }
                 if constexpr (st && DIAG == 11) {      // timing-only: halo loads kept alive without the LDS stores
                     if constexpr (h >= 17 && h <= 22) asm volatile("" ::"v"(rawreg[h - 17]));
@@ -432,6 +464,13 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
 
         // ---- prologue --------------------------------------------------------------------------------------------------------------
         raw_load(0);
+        if constexpr (PERSIST) {
+            // STAGGER: the two workgroups of a CU start together and run tiles of equal length, so their epilogues (no MFMAs for
+            // ~10 k cycles) tend to coincide and the matrix pipe idles (tools/wino4_persist_probe.py: 17 % of the time at cin = 64).
+            // The second-dispatched half of the grid starts m.stagger x 1024 cycles late, once, while its first loads are in flight.
+            if ((int)(blockIdx.x >> 3) >= (stride >> 1))
+                for (int k = 0; k < m.stagger; ++k) __builtin_amdgcn_s_sleep(16);
+        }
         raw_store(Rs);
         __syncthreads();
         raw_load(W4_KR * 4);                                // stages past the end read neighbouring data or zeros, never consumed
@@ -455,7 +494,23 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
             if constexpr (DIAG == 3) phase[2] = __builtin_amdgcn_s_memrealtime();
         } else {
             int ntile = 0;
+            // DIAG 4: shader-clock stamps of the persistent form: 0 tile start, 1 main-loop end, 2 after the barrier in front of
+            // the epilogue, 3 P values written + barrier, 4 P values read + barrier + next halo stored, 5 outputs stored,
+            // 6 accumulators cleared + barrier, 7 next tile's first transform done
+            auto tile_stamp = [&]() {
+                if constexpr (DIAG == 4) {
+                    tpx[7] = __builtin_amdgcn_s_memtime();
+                    if (a.dbg && lane_now() == 0 && ntile <= 32) {
+                        unsigned long long* d = a.dbg + (((size_t)blockIdx.x * 4 + WJ) * 32 + (ntile - 1)) * 8;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) d[q] = tpx[q];
+                        if (ntile == 1 && WJ == 0) a.dbg[(size_t)gridDim.x * 1024 + blockIdx.x] =
+                            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+                    }
+                }
+            };
             for (;;) {
+                if constexpr (DIAG == 4) tpx[0] = __builtin_amdgcn_s_memtime();
                 // the tile after this one (or this one again when the list is exhausted: its loads are then never consumed)
                 const int nitem = item + stride < hi ? item + stride : item;
                 const int nseg = seg_of(nitem);
@@ -464,9 +519,11 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 decode(nli, ntiles, m.s[nseg].n, nct_, npt, nimg);
                 const int ntx0 = (npt % ngtx) * 32, nty0 = (npt / ngtx) * 8;
                 const int wso_next = ((nct_ * 4 + wj) * nch) * 6144;
-                if (prio_mode) {
+                if (prio_mode & 1) {
                     if ((ntile + (int)((blockIdx.x >> 3) >= (stride >> 1))) & 1) __builtin_amdgcn_s_setprio(1);
                     else __builtin_amdgcn_s_setprio(0);
+                } else if (prio_mode & 2) {
+                    __builtin_amdgcn_s_setprio(0);
                 }
                 ++ntile;
                 // the halo loads run two stages ahead: once the current tile's last stage has been requested (in iteration
@@ -488,9 +545,13 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, wso + 6144, P0);
                 chunk(Rs, F, F, F, 0, nullptr, wso_next, P1);      // the ring's look-ahead continues in the next tile's weights
                 wso = wso_next;
+                if constexpr (DIAG == 4) tpx[1] = __builtin_amdgcn_s_memtime();
+                if (prio_mode & 2) __builtin_amdgcn_s_setprio(3);      // experiment: the MFMA-free phase of a tile at top priority
                 __syncthreads();
+                if constexpr (DIAG == 4) tpx[2] = __builtin_amdgcn_s_memtime();
                 epilogue();                                     // of (ct, img, tx0, ty0); also writes the next tile's first halo stage
-                if (item + stride >= hi) break;
+                if constexpr (DIAG == 4) tpx[5] = __builtin_amdgcn_s_memtime();
+                if (item + stride >= hi) { tpx[6] = tpx[5]; tile_stamp(); break; }
                 item += stride;
                 ct = nct_; img = nimg; tx0 = ntx0; ty0 = nty0; seg = nseg;
 #pragma unroll
@@ -498,12 +559,14 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
                 __syncthreads();
+                if constexpr (DIAG == 4) tpx[6] = __builtin_amdgcn_s_memtime();
                 raw_load(W4_KR * 4);
                 xf_addr();
                 xf_read3(Rs, 0); xf_cols(0);
                 xf_read3(Rs, 3); xf_cols(3);
                 rows_012(aq); rows_34(aq); rows_5();
                 aq[4] = o4; aq[5] = o5;
+                tile_stamp();
             }
         }
     };
@@ -564,6 +627,7 @@ static int check_wino4_shape(const ConvArgs& a, int src_mode) {
 // Channel tiles per group of the persistent walk: the largest divisor of cout / 32 whose transformed weights (cin x 32 G x 24
 // floats) fit W4_L2_WEIGHT_BYTES of an XCD's 4 MB L2 (the rest is left to the halos and outputs streaming through).
 constexpr size_t W4_L2_WEIGHT_BYTES = 3u << 20;
+constexpr int W4_STAGGER = 0;       // start delay of the second half of the persistent grid (x 1024 cycles); see the kernel
 static int walk_group(int cin, int cout) {
     const int nct = cout / 32;
     static const int force = tune_env("ADAIN_W4_CTG", 0);       // diagnostic build: 0 = automatic, -1 = all channel tiles, > 0 = that many
@@ -599,11 +663,13 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     static const int prio_env = tune_env("ADAIN_W4_PRIO", 1);
     const long long pgrid = persistent_grid();
     if (pgrid <= 0) { set_error("conv3x3_wino4: device query failed"); return -1; }
-    const bool persist = !a.dbg && a.cin <= persist_env && a.cin >= 2 * W4_KR && pgrid >= 8 && blocks >= 2 * pgrid;
+    const bool persist_ok = a.cin <= persist_env && a.cin >= 2 * W4_KR && pgrid >= 8 && blocks >= 2 * pgrid;
+    const bool persist = !a.dbg && persist_ok;
     const int items = (int)blocks;
     ConvSegs m{};
     m.count = 1;
     m.ctg = walk_group(a.cin, a.cout);
+    m.stagger = tune_env("ADAIN_W4_STAGGER", W4_STAGGER);
     m.s[0] = ConvSeg{a.in, a.out, a.n, a.H, a.W, a.Hs, a.Ws, a.tiles_x, a.tiles_y, 0};
     if (persist) {
         const dim3 pg((unsigned)pgrid);
@@ -615,11 +681,15 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     // timing / stamp builds of the one-tile form (tools/ only: libadain_hip_diag.so); selected by ADAIN_W4_DIAG when a stamp
     // buffer is set
     static const int diag_env = tune_env("ADAIN_W4_DIAG", 0);
+    if (a.dbg && diag_env == 4 && persist_ok && src_mode == SRC_DIRECT) {      // per-tile phase stamps of the persistent form
+        hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 4, true>), dim3((unsigned)pgrid), dim3(256), 0, s, a, m, items, prio_env);
+        return check_launch("conv3x3_wino4(diag)");
+    }
     if (a.dbg && src_mode == SRC_DIRECT) {
         switch (diag_env) {
 #define W4_DIAG_CASE(D) case D: hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, D>), g, dim3(256), 0, s, a, m, items, 0); break;
             W4_DIAG_CASE(2) W4_DIAG_CASE(3) W4_DIAG_CASE(5) W4_DIAG_CASE(6) W4_DIAG_CASE(7) W4_DIAG_CASE(8) W4_DIAG_CASE(9)
-            W4_DIAG_CASE(10) W4_DIAG_CASE(11) W4_DIAG_CASE(12)
+            W4_DIAG_CASE(10) W4_DIAG_CASE(11) W4_DIAG_CASE(12) W4_DIAG_CASE(13) W4_DIAG_CASE(14)
 #undef W4_DIAG_CASE
             default: hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 1>), g, dim3(256), 0, s, a, m, items, 0);
         }
@@ -636,6 +706,7 @@ int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int c
     ConvSegs m{};
     m.count = count;
     m.ctg = walk_group(layer.cin, layer.cout);
+    m.stagger = tune_env("ADAIN_W4_STAGGER", W4_STAGGER);
     long long total = 0;
     ConvArgs a = layer;
     for (int i = 0; i < count; ++i) {
