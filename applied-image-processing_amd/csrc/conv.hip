@@ -938,8 +938,8 @@ int conv3x3_auto_variant(const ConvArgs& a, int src_mode) {
 int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s) {
     if (a.cin % KC || a.cin < KC) { set_error("conv3x3: cin %d not a multiple of 16", a.cin); return -1; }
     if (a.H < 2 || a.W < 2 || a.n < 1) { set_error("conv3x3: H, W must be >= 2 (reflection pad), got %dx%d", a.H, a.W); return -1; }
-    if ((size_t)a.Hs * a.Ws * a.cin * 4 >= 0x7fffffffULL) {
-        set_error("conv3x3: per-image source tensor must stay below 2 GiB (32-bit buffer offsets)");
+    if ((size_t)a.Hs * a.Ws * a.cin * 4 >= 0x7fffffffULL || (size_t)a.H * a.W * a.cout * 4 >= 0x7fffffffULL) {
+        set_error("conv3x3: per-image source and output tensors must stay below 2 GiB (32-bit buffer offsets)");
         return -1;
     }
     if (variant < 0) variant = conv3x3_auto_variant(a, src_mode);

@@ -624,7 +624,10 @@ int launch_conv3x3_wino(const ConvArgs& a0, int src_mode, int mh, hipStream_t s)
     if (a.cin % WKC || a.cin < WKC) { set_error("conv3x3_wino: cin %d not a multiple of 8", a.cin); return -1; }
     if (a.cout % 64) { set_error("conv3x3_wino: cout %d not a multiple of 64", a.cout); return -1; }
     if (a.H < 2 || a.W < 2 || a.n < 1) { set_error("conv3x3_wino: H, W must be >= 2, got %dx%d", a.H, a.W); return -1; }
-    if ((size_t)a.Hs * a.Ws * a.cin * 4 >= 0x7fffffffULL) { set_error("conv3x3_wino: per-image source tensor must stay below 2 GiB"); return -1; }
+    if ((size_t)a.Hs * a.Ws * a.cin * 4 >= 0x7fffffffULL || (size_t)a.H * a.W * a.cout * 4 >= 0x7fffffffULL) {
+        set_error("conv3x3_wino: per-image source and output tensors must stay below 2 GiB (32-bit buffer offsets)");
+        return -1;
+    }
     if (src_mode == SRC_DIRECT) {
         if (a.Hs != a.H || a.Ws != a.W) { set_error("conv3x3_wino: direct mode needs Hs==H, Ws==W"); return -1; }
     } else if (src_mode == SRC_UP2X) {

@@ -13,6 +13,7 @@
 // area_pixel_compute_source_index, get_cubic_upsample_coefficients, nearest_neighbor_compute_source_index)
 // in fp32, including the accumulation order (inner sum over x, outer over y).
 #include "common.h"
+#include "device_utils.h"
 
 namespace adain {
 
@@ -347,14 +348,17 @@ int launch_quantize_u8(const float* in, uint8_t* out, int n, int c, int h, int w
 // warp(prev)(y, x) = bilinear sample of prev at (x + flow[0][y][x], y + flow[1][y][x]) with cv2.BORDER_REFLECT
 // (fedcba|abcdefgh|hgfedcb), in cv2.remap's own uint8 fixed-point arithmetic (below).  cv2 is not installed in the build
 // image, so the fixed-point restatement is checked against the oracle only (parity unpinned against OpenCV itself).
-__device__ __forceinline__ int reflect_border(int v, int n) {
-    if ((unsigned)v < (unsigned)n) return v;                      // inside the frame: almost every tap
-    const int once = v < 0 ? -1 - v : 2 * n - 1 - v;              // one reflection covers displacements up to a frame size
-    if ((unsigned)once < (unsigned)n) return once;
+__device__ __attribute__((noinline)) int reflect_border_far(int v, int n) {
     const int p = 2 * n;      // BORDER_REFLECT has period 2n: ...cba|abc...xyz|zyx...
     v %= p;
     if (v < 0) v += p;
     return v < n ? v : p - 1 - v;
+}
+__device__ __forceinline__ int reflect_border(int v, int n) {
+    if ((unsigned)v < (unsigned)n) return v;                      // inside the frame: almost every tap
+    const int once = v < 0 ? -1 - v : 2 * n - 1 - v;              // one reflection covers displacements up to a frame size
+    if (__builtin_expect((unsigned)once < (unsigned)n, 1)) return once;
+    return reflect_border_far(v, n);                              // a displacement beyond a whole frame: out of line (integer modulo)
 }
 
 // cv2.remap(uint8, float maps, INTER_LINEAR) is fixed point (OpenCV imgwarp: INTER_BITS = 5, INTER_REMAP_COEF_BITS = 15):
@@ -379,18 +383,34 @@ __device__ __forceinline__ WarpTap warp_tap(int x, int y, float fx_, float fy_, 
     return t;
 }
 
-__device__ __forceinline__ unsigned warp_blend1(const uint8_t* __restrict__ prev, const WarpTap& t, int ch, unsigned cur, float alpha,
-                                                float one_minus_alpha) {
-    const int wv = ((int)prev[t.o00 + ch] * t.w00 + (int)prev[t.o01 + ch] * t.w01 + (int)prev[t.o10 + ch] * t.w10 +
-                    (int)prev[t.o11 + ch] * t.w11 + (1 << 14)) >> 15;          // <= 255 by construction
-    const float a = alpha * ((float)cur / 255.0f);
-    const float bq = one_minus_alpha * ((float)wv / 255.0f);
+// v / 255.0f for an integer-valued v in [0, 2^24), correctly rounded (= numpy's float32 division): one Newton step on
+// v * RN(1/255) with the exact residual.  v / 255 is never within 2^-32 (relative) of a rounding boundary (255 does not
+// divide a power of two), while the corrected quotient is within 2^-47 of the exact one, so the final rounding is the exact
+// quotient's.  Replaces the ~10-instruction IEEE division sequence, six times per pixel.
+__device__ __forceinline__ float div255(float v) {
+    const float r = 1.0f / 255.0f;
+    const float q = v * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, v), r, q);
+}
+
+__device__ __forceinline__ unsigned blend1(int wv, unsigned cur, float alpha, float one_minus_alpha) {
+    const float a = alpha * div255((float)cur);
+    const float bq = one_minus_alpha * div255((float)wv);
     const float b = (a + bq) * 255.0f;
     return (unsigned)fminf(fmaxf(b, 0.f), 255.f);
 }
 
+__device__ __forceinline__ unsigned warp_blend1(const uint8_t* __restrict__ prev, const WarpTap& t, int ch, unsigned cur, float alpha,
+                                                float one_minus_alpha) {
+    const int wv = ((int)prev[t.o00 + ch] * t.w00 + (int)prev[t.o01 + ch] * t.w01 + (int)prev[t.o10 + ch] * t.w10 +
+                    (int)prev[t.o11 + ch] * t.w11 + (1 << 14)) >> 15;          // <= 255 by construction
+    return blend1(wv, cur, alpha, one_minus_alpha);
+}
+
 // c == 3, h*w % 4 == 0: a thread owns 4 consecutive pixels (flat index): two b128 flow loads, 12 current bytes as three
-// dwords, 12 output bytes as one 96-bit store; the 48 gathered bytes of the previous frame stay byte loads
+// dwords, 12 output bytes as one 96-bit store.  The two taps of a row are neighbouring pixels (BORDER_REFLECT is continuous:
+// |x1 - x0| <= 1), i.e. 6 consecutive bytes of the previous frame: ONE bounds-checked 8-byte buffer load at the left one of
+// the two (2 gathers per pixel instead of 12 byte loads).
 __global__ __launch_bounds__(256) void warp_blend_u8_rgb4_kernel(const uint8_t* __restrict__ cur, const uint8_t* __restrict__ prev,
                                                                  const float* __restrict__ flow, uint8_t* __restrict__ out, int h, int w,
                                                                  float alpha, float one_minus_alpha) {
@@ -399,16 +419,42 @@ __global__ __launch_bounds__(256) void warp_blend_u8_rgb4_kernel(const uint8_t* 
     if (i >= total) return;
     const f32x4 fx = *(const f32x4*)(flow + i), fy = *(const f32x4*)(flow + total + i);
     using u32x3 = __attribute__((ext_vector_type(3))) unsigned;
+    using u32x2 = __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned;
     const u32x3 cw = *(const u32x3*)(cur + (size_t)i * 3);
+    const rsrc_t pr = make_rsrc(prev, (unsigned)total * 3u);
+    const int nbytes = total * 3;
+    // 8 bytes of the previous frame at byte offset `off` (the 6 that matter are inside the frame); the last two pixels of the
+    // frame would read past its end: those assemble their bytes one by one (a buffer load that crosses the end returns zeros)
+    auto load8 = [&](int off) -> unsigned long long {
+        if (__builtin_expect(off + 8 <= nbytes, 1)) {
+            const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(pr, off, 0, 0);
+            return (unsigned long long)r[0] | ((unsigned long long)r[1] << 32);
+        }
+        unsigned long long v = 0;
+        for (int j = 0; j < 6 && off + j < nbytes; ++j) v |= (unsigned long long)prev[off + j] << (8 * j);
+        return v;
+    };
     int y = i / w, x = i - y * w;
     unsigned by[12];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const WarpTap t = warp_tap(x, y, fx[k], fy[k], h, w, 3);
+        const float mx = (float)x + fx[k], my = (float)y + fy[k];
+        const int ix = __float2int_rn(mx * 32.0f), iy = __float2int_rn(my * 32.0f);
+        const int sx = clamp_short(ix >> 5), sy = clamp_short(iy >> 5), qx = ix & 31, qy = iy & 31;
+        const int x0 = reflect_border(sx, w), x1 = reflect_border(sx + 1, w);
+        const int y0 = reflect_border(sy, h), y1 = reflect_border(sy + 1, h);
+        const int w00 = (32 - qx) * (32 - qy) * 32, w01 = qx * (32 - qy) * 32, w10 = (32 - qx) * qy * 32, w11 = qx * qy * 32;
+        const int xm = min(x0, x1);
+        // byte shifts of tap 0 / tap 1 inside the 8 loaded bytes: the left pixel sits at 0, its right neighbour at 24 bits
+        const int s0 = x0 == xm ? 0 : 24, s1 = x1 == xm ? 0 : 24;
+        const unsigned long long v0 = load8((y0 * w + xm) * 3), v1 = load8((y1 * w + xm) * 3);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
+            const int p00 = (int)((v0 >> (s0 + 8 * ch)) & 255u), p01 = (int)((v0 >> (s1 + 8 * ch)) & 255u);
+            const int p10 = (int)((v1 >> (s0 + 8 * ch)) & 255u), p11 = (int)((v1 >> (s1 + 8 * ch)) & 255u);
+            const int wv = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
             const int b = 3 * k + ch;
-            by[b] = warp_blend1(prev, t, ch, (cw[b >> 2] >> (8 * (b & 3))) & 255u, alpha, one_minus_alpha);
+            by[b] = blend1(wv, (cw[b >> 2] >> (8 * (b & 3))) & 255u, alpha, one_minus_alpha);
         }
         if (++x == w) { x = 0; ++y; }
     }

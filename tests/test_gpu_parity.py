@@ -303,6 +303,18 @@ def test_video_warp_blend_vs_oracle(rt):
     out = rt.warp_blend_u8(T(cur).cuda(), T(prev).cuda(), T(flow).cuda(), 0.7).cpu().numpy()
     ref = O.warp_blend_u8(cur, prev, flow, 0.7)
     assert np.array_equal(out, ref)                        # fixed-point warp + uncontracted fp32 blend: bit-exact
+    # every uint8 value through both divisions by 255 (the kernel divides by a corrected reciprocal: must equal numpy's float32 /),
+    # several alphas, with a 4-pixel-aligned frame (vector kernel) and an odd one (scalar kernel)
+    for hh, ww in ((16, 64), (15, 67)):
+        ramp = (np.arange(hh * ww * 3) % 256).astype(np.uint8).reshape(hh, ww, 3)
+        other = ((np.arange(hh * ww * 3) * 7 + 3) % 256).astype(np.uint8).reshape(hh, ww, 3)
+        fl = synth.uniform_sym(84, (2, hh, ww), 1.5)
+        for al in (0.7, 0.5, 0.123, 1.0, 0.0):
+            got = rt.warp_blend_u8(T(ramp).cuda(), T(other).cuda(), T(fl).cuda(), al).cpu().numpy()
+            assert np.array_equal(got, O.warp_blend_u8(ramp, other, fl, al)), (hh, ww, al)
+    # displacements of several frame sizes (the out-of-line reflection path)
+    big = synth.uniform_sym(85, (2, h, w), 400.0)
+    assert np.array_equal(rt.warp_blend_u8(T(cur).cuda(), T(prev).cuda(), T(big).cuda(), 0.7).cpu().numpy(), O.warp_blend_u8(cur, prev, big, 0.7))
     # zero flow, alpha = 1 reproduces the current frame exactly; alpha = 0 the previous one
     z = torch.zeros(2, h, w).cuda()
     assert np.array_equal(rt.warp_blend_u8(T(cur).cuda(), T(prev).cuda(), z, 1.0).cpu().numpy(), cur)
@@ -507,3 +519,16 @@ def test_encode_multi_is_bitwise_the_separate_encodes(rt, weights, sizes):
         close(multi[-1].permute(0, 3, 1, 2), O.encode(vgg_sd, xs[-1].cpu()))
     with pytest.raises(rt.AdainHipError):
         rt.encode_multi(xs + xs + xs, packed)                     # more than four segments
+
+
+def test_two_gib_limit_is_an_error_not_a_wraparound(rt, weights):
+    """Per-image activations use 32-bit buffer offsets: a 64-channel full-resolution layer of 2 GiB or more (content above
+    ~8.39 Mpixels) must be refused by the first layer already, before anything is launched with a wrapped offset."""
+    vgg_sd, dec_sd = weights
+    packed = rt.pack_encoder(vgg_sd, torch.device("cuda", 0))
+    x = torch.zeros((1, 3, 2160, 4096), device="cuda")           # 8.85 Mpixels: 64 channels = 2.27 GB
+    with pytest.raises(rt.AdainHipError, match="2 GiB"):
+        rt.encode(x, packed)
+    feat = torch.zeros((1, 270, 512, 512), device="cuda")        # decoder output 2160 x 4096
+    with pytest.raises(rt.AdainHipError, match="2 GiB"):
+        rt.decode(feat, rt.pack_decoder(dec_sd, torch.device("cuda", 0)))
