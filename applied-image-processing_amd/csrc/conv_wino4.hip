@@ -33,6 +33,10 @@
 namespace adain {
 
 namespace {
+#ifndef W4_GROUP
+#define W4_GROUP 1                           // 1: one MFMA per scheduling region (default); 8: eight MFMAs back to back, then their work
+#endif
+static_assert(W4_GROUP == 1 || W4_GROUP == 8, "the burst schedule is laid out for groups of 8 (one pair of row positions)");
 constexpr int W4_KR = 16;                    // channels per raw stage = 2 chunks of 8
 constexpr int W4_RSTR = W4_KR + 4;           // floats per halo pixel (80 B = 5 quads: an odd number of 16-byte bank quads)
 constexpr int W4_HALO_W = 34, W4_HALO_H = 10;
@@ -232,7 +236,8 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
             const int hy = (hp * 241) >> 13, hx = hp - hy * W4_HALO_W;          // hp / 34 for hp < 400
             sa[k] = hp < W4_HALO ? (hx & 1) * W4_PLANE + hy * W4_PROW + (hx >> 1) * W4_RSTR + q * 4
                                  : W4_TAIL + (hp - W4_HALO) * W4_RSTR + q * 4;
-        }
+            asm volatile("" : "+v"(sa[k]));      // held in a register: left alone the compiler recomputes it (8 vector
+        }                                        // instructions per item and stage, and every one of them costs matrix-pipe time)
     }
     auto raw_store = [&](float* buf) {
 #pragma unroll
@@ -369,11 +374,13 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         auto rows_5 = [&]() { o5 = 4.f * f[1] + (f[5] - 5.f * f[3]); };
 
         f32x4 aq[6], t1, t2, t3, d31;
-        int xaddr = 0;          // this lane's patch origin in the halo image (floats), rebuilt at the start of every chunk
-        auto xf_addr = [&]() {
-            const int l = lane_now(), li = l & 31, lh = l >> 5;
+        int xaddr = 0;          // this lane's patch origin in the halo image (floats): computed once, held in a register
+        {
+            const int li = lane & 31, lh = lane >> 5;
             xaddr = (4 * (li >> 4)) * W4_PROW + (li & 15) * W4_RSTR + 4 * lh;
-        };
+            asm volatile("" : "+v"(xaddr));
+        }
+        auto xf_addr = [&]() {};
         // patch pixel (row a, column c of the 6 x 4 patch) relative to xaddr: plane c & 1, plane column + (c >> 1)
         auto poff = [](int a, int c) { return (c & 1) * W4_PLANE + a * W4_PROW + (c >> 1) * W4_RSTR; };
         auto xf_read3 = [&](const float* rb, int a0) {
@@ -402,15 +409,27 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         auto chunk = [&](const float* nsrc, auto XFC, auto STC, auto LDC, int raw_soff, float* store_to, int wnext, auto PARC) {
             constexpr bool do_xf = decltype(XFC)::value, st = decltype(STC)::value, ld = decltype(LDC)::value;
             constexpr int par = RING12 ? decltype(PARC)::value : 0;
-            auto half = [&](auto HH) {
-                constexpr int h = decltype(HH)::value;          // 0..23: mini-step m = h / 2 (d = m / 4, s = m % 4), b = second MFMA
-                constexpr int m = h / 2, b = h & 1, d = m / 4, sidx = m & 3, r = 2 * d + b;
+            // Schedule: GRP == 1 (default) = one MFMA per scheduling region followed by its share of the chunk's other work;
+            // GRP == 8 (-DW4_GROUP=8) = the eight MFMAs of a pair of row positions back to back, then their regions' work in one
+            // burst.  A plain fp32 vector instruction takes matrix-pipe time on gfx950 (tools/probes/mfma_valu_probe.hip: a bare
+            // stream of fp32 MFMAs with 5 v_fma_f32 each reaches 113-119 TFLOP/s alternating 1 : 5 and 126-129 in bursts of 4 : 20 or
+            // more), but in this kernel the burst form measured 0.6 % SLOWER (3.64 vs 3.62 ms per config-2 step): what counts is
+            // the NUMBER of vector instructions per MFMA (see `sa`, `xaddr`), not their placement.
+            constexpr int GRP = W4_GROUP;
+            auto mf = [&](auto HH) {
+                constexpr int h = decltype(HH)::value, m = h / 2, b = h & 1, d = m / 4, sidx = m & 3, r = 2 * d + b;
                 if constexpr ((DIAG == 1 || DIAG == 2) && (h % 8) == 0) {
                     const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
                     if (lane_now() == 0 && nlog < 96) steplog[WJ * 96 + nlog] = tnow;
                     ++nlog;
                 }
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[6 * par + r][sidx], aq[r][sidx], acc[r], 0, 0, 0);
+            };
+            // region (1 MFMA : work) schedule, and the burst schedule's regions for the same pieces of work
+            constexpr int H_COLS0 = GRP == 1 ? 10 : 8, H_READ1 = GRP == 1 ? 11 : 9, H_COLS3 = GRP == 1 ? 20 : 16, H_ROWS = GRP == 1 ? 21 : 17;
+            auto work = [&](auto HH) {
+                constexpr int h = decltype(HH)::value;          // 0..23: mini-step m = h / 2 (d = m / 4, s = m % 4), b = second MFMA
+                constexpr int m = h / 2, b = h & 1;
                 // ---- weight ring: (this chunk) slots 4, 5 at mini-steps 0, 1; (next chunk) slots 0, 1 at 4, 5; slots 2, 3 at 8, 9 ----
                 if constexpr (DIAG == 13 || DIAG == 14) {
                     // timing-only: no weight loads in the main loop (the ring keeps its first fragments)
@@ -430,18 +449,15 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                     rawreg[k] = buf_load4(src, roff[k], raw_soff);
                 }
                 // ---- input transform of the next chunk ----
-                // (one LDS instruction per region: six patch reads behind one MFMA hold the wave for ~200 cycles while the LDS
-                // queue takes them - timing-only builds without the patch reads ran 16 % faster, without the transform's
-                // arithmetic no faster than that)
                 if constexpr (do_xf && DIAG != 5) {
                     if constexpr (h == 0) xf_addr();
                     if constexpr (h >= 1 && h <= 6 && DIAG != 6) xf_read1(nsrc, 0, std::integral_constant<int, h - 1>{});
-                    if constexpr (h == 10) xf_cols(0);                                             // four regions after the last read
-                    if constexpr (h >= 11 && h <= 16 && DIAG != 6) xf_read1(nsrc, 3, std::integral_constant<int, h - 11>{});
-                    if constexpr (h == 20) xf_cols(3);
-                    if constexpr (h == 21) { aq[0] = 4.f * f[0] + (f[4] - 5.f * f[2]); t1 = f[4] - 4.f * f[2]; t2 = f[3] - 4.f * f[1]; }   // fragments 0..3: dead since region 15
-                    if constexpr (h == 22) { aq[1] = t1 + t2; aq[2] = t1 - t2; t3 = f[4] - f[2]; d31 = f[3] - f[1]; }
-                    if constexpr (h == 23) { aq[3] = t3 + 2.f * d31; o4 = t3 - 2.f * d31; o5 = 4.f * f[1] + (f[5] - 5.f * f[3]); }
+                    if constexpr (h == H_COLS0) xf_cols(0);
+                    if constexpr (h >= H_READ1 && h <= H_READ1 + 5 && DIAG != 6) xf_read1(nsrc, 3, std::integral_constant<int, h - H_READ1>{});
+                    if constexpr (h == H_COLS3) xf_cols(3);
+                    if constexpr (h == H_ROWS) { aq[0] = 4.f * f[0] + (f[4] - 5.f * f[2]); t1 = f[4] - 4.f * f[2]; t2 = f[3] - 4.f * f[1]; }   // fragments 0..3: dead since region 15
+                    if constexpr (h == H_ROWS + 1) { aq[1] = t1 + t2; aq[2] = t1 - t2; t3 = f[4] - f[2]; d31 = f[3] - f[1]; }
+                    if constexpr (h == H_ROWS + 2) { aq[3] = t3 + 2.f * d31; o4 = t3 - 2.f * d31; o5 = 4.f * f[1] + (f[5] - 5.f * f[3]); }
                 }
                 // ---- halo store of the stage loaded one stage ago ----
                 if constexpr (st && DIAG != 8 && DIAG != 11) {
@@ -451,10 +467,16 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                     if constexpr (h >= 17 && h <= 22) asm volatile("" ::"v"(rawreg[h - 17]));
                 }
                 if constexpr (do_xf && h == 23) { aq[4] = o4; aq[5] = o5; }
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // the MFMA first, everything else behind it
+            };
+            auto group = [&](auto GG) {
+                constexpr int g0 = decltype(GG)::value * GRP;
+                [&]<int... I>(std::integer_sequence<int, I...>) { (mf(std::integral_constant<int, g0 + I>{}), ...); }(std::make_integer_sequence<int, GRP>{});
+                if constexpr (GRP > 1) __builtin_amdgcn_sched_barrier(0);
+                [&]<int... I>(std::integer_sequence<int, I...>) { (work(std::integral_constant<int, g0 + I>{}), ...); }(std::make_integer_sequence<int, GRP>{});
+                if constexpr (GRP == 1) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // the MFMA first, everything else behind it
                 __builtin_amdgcn_sched_barrier(0);
             };
-            [&]<int... I>(std::integer_sequence<int, I...>) { (half(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, 24>{});
+            [&]<int... G>(std::integer_sequence<int, G...>) { (group(std::integral_constant<int, G>{}), ...); }(std::make_integer_sequence<int, 24 / GRP>{});
             wso += 6144;
         };
         constexpr std::true_type T{};
