@@ -292,3 +292,58 @@ def test_checkpoint_cache_notices_foreign_weights(rt, weights, tmp_path):
         net.vgg[2].weight.mul_(0.5)                                                  # in-place edit
     c = np.asarray(Image.open(t.adain_inference(cimg, simg, file_name="c", **kw)))
     assert np.array_equal(a, c)
+
+
+def test_video_caller_from_directories(rt, engine, weights, tmp_path):
+    """video.apply_style_transfer_multi_ada (reference video/utils.py:297-372) from frame / style directories with the depth and
+    flow providers plugged: output files keep the frame names, frame 0 is the stylised + resized frame, later frames the
+    recurrence; compared with the oracle chain (<= 2 levels: a 1-level difference of a stylised frame can move a blended pixel)."""
+    from PIL import Image
+
+    import applied_image_processing_amd.jobs as jobs
+    from applied_image_processing_amd import video
+    from applied_image_processing_amd.AdaIN import test as t
+
+    vgg_sd, dec_sd = weights
+    cdir, sdir, odir = tmp_path / "frames", tmp_path / "styles", tmp_path / "out"
+    cdir.mkdir(); sdir.mkdir()
+    n = 4
+    for i in range(n):
+        Image.fromarray(u8img(450 + i, 72, 128)).save(cdir / f"frame_{i:04d}.png")
+    for i in range(2):
+        Image.fromarray(u8img(460 + i, 64, 64)).save(sdir / f"style_{i}.png")
+    flows = [synth.uniform_sym(470 + i, (2, 36, 64), 2.0) for i in range(n - 1)]
+    calls = []
+
+    def flow_provider(prev_path, cur_path, target_resolution, method):
+        calls.append((os.path.basename(prev_path), os.path.basename(cur_path), tuple(target_resolution), method))
+        return flows[len(calls) - 1]
+
+    t.set_depth_provider(lambda img: T(synth.smooth_depth(480 + img.size[0] % 7, img.size[1], img.size[0])))
+    video.set_flow_provider(flow_provider)
+    try:
+        out = video.apply_style_transfer_multi_ada(str(cdir), str(sdir), str(odir), flow_method="dualtvl1", alpha=0.7,
+                                                   target_resolution=(64, 36), engine=engine)
+    finally:
+        t.set_depth_provider(None)
+        video.set_flow_provider(None)
+    assert out == odir and sorted(os.listdir(odir)) == [f"frame_{i:04d}.png" for i in range(n)]
+    assert calls == [(f"frame_{i:04d}.png", f"frame_{i + 1:04d}.png", (64, 36), "dualtvl1") for i in range(n - 1)]
+    # oracle chain
+    tf, stf = t.test_transform(256, False), t.test_transform(512, False)
+    styles = [stf(Image.open(sdir / f"style_{i}.png")).unsqueeze(0) for i in range(2)]
+    sched = jobs.style_schedule(n, 2)
+    depth = T(synth.smooth_depth(480 + 128 % 7, 72, 128))
+    small = []
+    for i in range(n):
+        c = tf(Image.open(cdir / f"frame_{i:04d}.png")).unsqueeze(0)
+        with torch.no_grad():
+            u8 = O.quantize_u8(O.style_transfer(vgg_sd, dec_sd, c, styles[sched[i]], depth, 1.0, 0.30, 20))[0].numpy()
+        small.append(O.resize_area_u8(u8, (64, 36)))
+    want = O.temporal_blend(np.stack(small), np.stack(flows), 0.7)
+    for i in range(n):
+        got = np.asarray(Image.open(odir / f"frame_{i:04d}.png"))
+        d = np.abs(got.astype(int) - want[i].astype(int))
+        assert got.shape == (36, 64, 3) and d.max() <= 2 and (d > 0).mean() < 0.02, (i, d.max(), (d > 0).mean())
+    with pytest.raises(RuntimeError, match="provider"):
+        video.estimate_optical_flow("a", "b", (64, 36))
