@@ -76,6 +76,56 @@ __global__ __launch_bounds__(256, 2) void kb(float* out, unsigned long long* cyc
     (void)cyc;
 }
 
+// packed fp32: NP v_pk_fma_f32 (two FMAs per lane each) per MFMA, against 2 NP plain v_fma_f32
+template <int NP>
+__global__ __launch_bounds__(256, 2) void kp(float* out, int iters) {
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    __shared__ float pad[18000];
+    if (threadIdx.x == 0) pad[0] = 0.f;
+    f32x16 acc[6];
+    for (int i = 0; i < 6; ++i)
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    f32x2 v[8];
+    for (int i = 0; i < 8; ++i) v[i] = f32x2{threadIdx.x * 0.01f + i, threadIdx.x * 0.02f - i};
+    const float a = threadIdx.x * 0.001f + 1.f, b = 0.5f + threadIdx.x * 0.002f;
+    const f32x2 c = {1.0001f, 0.9999f}, d = {b, a};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int h = 0; h < 24; ++h) {
+            acc[h % 6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[h % 6], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NP; ++n) v[(h + n) & 7] = __builtin_elementwise_fma(v[(h + n) & 7], c, d);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = pad[0];
+    for (int i = 0; i < 6; ++i)
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    for (int i = 0; i < 8; ++i) s += v[i][0] + v[i][1];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int NP>
+static void run_packed() {
+    const int blocks = 512, iters = 400;
+    float* out;
+    hipMalloc(&out, blocks * 256 * sizeof(float));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((kp<NP>), dim3(blocks), dim3(256), 0, 0, out, iters);
+    hipEventRecord(e0, 0);
+    for (int rep = 0; rep < 5; ++rep) hipLaunchKernelGGL((kp<NP>), dim3(blocks), dim3(256), 0, 0, out, iters);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = 5.0 * blocks * 4 * (double)iters * 24 * 4096;
+    printf("packed: %d v_pk_fma_f32 per MFMA (= %d plain FMAs of work), 2 waves/SIMD: %.1f TFLOP/s\n", NP, 2 * NP, flops / (ms * 1e-3) / 1e12);
+    hipFree(out);
+}
+
 template <int NV, int G>
 static void run_batched() {
     const int blocks = 512, iters = 400;
@@ -135,5 +185,6 @@ int main() {
     run<0, 1, true>(); run<5, 1, true>();
     run_batched<5, 1>(); run_batched<5, 2>(); run_batched<5, 4>(); run_batched<5, 6>(); run_batched<5, 12>(); run_batched<5, 24>();
     run_batched<3, 1>(); run_batched<3, 4>(); run_batched<3, 12>();
+    run_packed<1>(); run_packed<2>(); run_packed<3>(); run_packed<4>();
     return 0;
 }
