@@ -253,10 +253,12 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     for (int r = 0; r < (RING12 ? 6 : 4); ++r) bq[r] = buf_load4(wsr, wvo, wso + r * 1024);
 
     f32x16 acc[6];
+    if constexpr (!PERSIST) {       // the persistent form starts every tile with MFMAs on a zero C operand
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+        for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+    }
 
     // ---- epilogue (a lambda: the persistent form runs it inside the tile loop) ------------------------------------------------------
     // lane (li = tile, lh): acc[r][e16] = M[row r][column wj][channel 8 (e16 >> 2) + 4 lh + (e16 & 3)][tile li]
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         const int oy = ty0 + 4 * (tl >> 4), ox = tx0 + 2 * (tl & 15);
         const int cbyte = (ct * 32 + 4 * q8) * 4;
         const bool colok0 = ox < eW, colok1 = ox + 1 < eW;
+        const float relu_lo = a.relu ? 0.f : -__builtin_inff();
         f32x4 y[4][2], P[4][4];
 #pragma unroll
         for (int ap = 0; ap < 4; ++ap)
@@ -313,10 +316,12 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         for (int ap = 0; ap < 4; ++ap) {
             y[ap][0] = P[ap][0] + P[ap][1] + P[ap][2] + bias4;          // A2 = columns (1,1,1,0), (0,1,-1,-1)
             y[ap][1] = P[ap][1] - P[ap][2] - P[ap][3] + bias4;
-            if (a.relu) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                y[ap][0] = max4(y[ap][0], z);
-                y[ap][1] = max4(y[ap][1], z);
+            // ReLU as ONE v_med3_f32 per element, max(y, lo) = med3(y, lo, +inf) with lo = 0 or -inf (no ReLU): fmaxf costs two
+            // instructions here (a canonicalising v_max before the real one) and the branch around it a dozen register copies
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[ap][0][e] = __builtin_amdgcn_fmed3f(y[ap][0][e], relu_lo, __builtin_inff());
+                y[ap][1][e] = __builtin_amdgcn_fmed3f(y[ap][1][e], relu_lo, __builtin_inff());
             }
         }
         if (a.pool_out) {
@@ -406,8 +411,12 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         // 412 cycles per 4 instead of 256 + issue overheads), and left to itself the scheduler builds exactly those chains.
         // XF: transform the next chunk's patches meanwhile; ST: the last third also writes the staged halo registers to LDS;
         // LD: the halo loads two stages ahead.  Weight ring: slot = row position, refilled as soon as its MFMAs have issued.
-        auto chunk = [&](const float* nsrc, auto XFC, auto STC, auto LDC, int raw_soff, float* store_to, int wnext, auto PARC) {
+        auto chunk = [&](const float* nsrc, auto XFC, auto STC, auto LDC, int raw_soff, float* store_to, int wnext, auto PARC,
+                         auto FIRSTC) {
             constexpr bool do_xf = decltype(XFC)::value, st = decltype(STC)::value, ld = decltype(LDC)::value;
+            // FIRST: the tile's first chunk - every accumulator's first MFMA takes a zero C operand (an inline constant) instead of
+            // a cleared register: no 96 v_mov per tile (vector instructions cost this kernel matrix-pipe time)
+            constexpr bool first = decltype(FIRSTC)::value;
             constexpr int par = RING12 ? decltype(PARC)::value : 0;
             // Schedule: GRP == 1 (default) = one MFMA per scheduling region followed by its share of the chunk's other work;
             // GRP == 8 (-DW4_GROUP=8) = the eight MFMAs of a pair of row positions back to back, then their regions' work in one
@@ -423,7 +432,12 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                     if (lane_now() == 0 && nlog < 96) steplog[WJ * 96 + nlog] = tnow;
                     ++nlog;
                 }
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[6 * par + r][sidx], aq[r][sidx], acc[r], 0, 0, 0);
+                if constexpr (first && sidx == 0) {
+                    constexpr f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[6 * par + r][sidx], aq[r][sidx], zero, 0, 0, 0);
+                } else {
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[6 * par + r][sidx], aq[r][sidx], acc[r], 0, 0, 0);
+                }
             };
             // region (1 MFMA : work) schedule, and the burst schedule's regions for the same pieces of work
             constexpr int H_COLS0 = GRP == 1 ? 10 : 8, H_READ1 = GRP == 1 ? 11 : 9, H_COLS3 = GRP == 1 ? 20 : 16, H_ROWS = GRP == 1 ? 21 : 17;
@@ -507,12 +521,12 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
             for (int s = 0; s + 1 < nst; ++s) {
                 const float* cur = Rs + (s & 1) * W4_RBUF;
                 float* nxt = Rs + ((s + 1) & 1) * W4_RBUF;
-                chunk(cur + 8, T, T, F, 0, nxt, wso + 6144, P0);                // channels 0..7; prepares 8..15; writes the next stage's halo
+                chunk(cur + 8, T, T, F, 0, nxt, wso + 6144, P0, F);                // channels 0..7; prepares 8..15; writes the next stage's halo
                 if constexpr (DIAG != 7) __syncthreads();
-                chunk(nxt, T, F, T, (s + 2) * W4_KR * 4, nullptr, wso + 6144, P1);      // channels 8..15; prepares the next stage; loads two stages ahead
+                chunk(nxt, T, F, T, (s + 2) * W4_KR * 4, nullptr, wso + 6144, P1, F);      // channels 8..15; prepares the next stage; loads two stages ahead
             }
-            chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, wso + 6144, P0);
-            chunk(Rs, F, F, F, 0, nullptr, wso + 6144, P1);
+            chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, wso + 6144, P0, F);
+            chunk(Rs, F, F, F, 0, nullptr, wso + 6144, P1, F);
             if constexpr (DIAG == 3) phase[2] = __builtin_amdgcn_s_memrealtime();
         } else {
             int ntile = 0;
@@ -556,16 +570,22 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                     src = src_of(m.s[nseg].in, m.s[nseg].Hs, m.s[nseg].Ws, nimg);
                 };
                 if (nst == 2) next_halo();
-                for (int s = 0; s + 1 < nst; ++s) {
+                {   // stage 0, peeled: its first chunk starts the tile's accumulators (FIRST)
+                    chunk(Rs + 8, T, T, F, 0, Rs + W4_RBUF, wso + 6144, P0, T);
+                    __syncthreads();
+                    chunk(Rs + W4_RBUF, T, F, T, nst == 2 ? 0 : 2 * W4_KR * 4, nullptr, wso + 6144, P1, F);
+                    if (nst == 3) next_halo();
+                }
+                for (int s = 1; s + 1 < nst; ++s) {
                     const float* cur = Rs + (s & 1) * W4_RBUF;
                     float* nxt = Rs + ((s + 1) & 1) * W4_RBUF;
-                    chunk(cur + 8, T, T, F, 0, nxt, wso + 6144, P0);
+                    chunk(cur + 8, T, T, F, 0, nxt, wso + 6144, P0, F);
                     __syncthreads();
-                    chunk(nxt, T, F, T, s == nst - 2 ? 0 : (s + 2) * W4_KR * 4, nullptr, wso + 6144, P1);
+                    chunk(nxt, T, F, T, s == nst - 2 ? 0 : (s + 2) * W4_KR * 4, nullptr, wso + 6144, P1, F);
                     if (s == nst - 3) next_halo();
                 }
-                chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, wso + 6144, P0);
-                chunk(Rs, F, F, F, 0, nullptr, wso_next, P1);      // the ring's look-ahead continues in the next tile's weights
+                chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, wso + 6144, P0, F);
+                chunk(Rs, F, F, F, 0, nullptr, wso_next, P1, F);      // the ring's look-ahead continues in the next tile's weights
                 wso = wso_next;
                 if constexpr (DIAG == 4) tpx[1] = __builtin_amdgcn_s_memtime();
                 if (prio_mode & 2) __builtin_amdgcn_s_setprio(3);      // experiment: the MFMA-free phase of a tile at top priority
@@ -576,11 +596,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 if (item + stride >= hi) { tpx[6] = tpx[5]; tile_stamp(); break; }
                 item += stride;
                 ct = nct_; img = nimg; tx0 = ntx0; ty0 = nty0; seg = nseg;
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
-                __syncthreads();
+                __syncthreads();                                // (the accumulators are not cleared: see FIRST)
                 if constexpr (DIAG == 4) tpx[6] = __builtin_amdgcn_s_memtime();
                 raw_load(W4_KR * 4);
                 xf_addr();
