@@ -209,14 +209,29 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     int roff[W4_RITEMS];
     auto halo_offsets = [&](int x0, int y0, int H, int W, int Ws) {
         const int t = PERSIST ? (lane_now() | (wj << 6)) : tid;        // persistent: recomputed per tile, nothing hoisted
+        // a tile whose 10 x 34 halo lies inside the image needs no reflection (92 % of the tiles at 1024 x 1024): the uniform
+        // branch saves 14 of the 27 vector instructions per item, 84 per tile and wave
+        const bool interior = PERSIST && y0 >= 1 && y0 + W4_HALO_H - 1 <= H && x0 >= 1 && x0 + W4_HALO_W - 1 <= W;
+        if (interior) {
 #pragma unroll
-        for (int k = 0; k < W4_RITEMS; ++k) {
-            const int idx = t + k * 256;
-            const int hp = min(idx >> 2, W4_HALO - 1), q = idx & 3;
-            const int hy = hp / W4_HALO_W, hx = hp - hy * W4_HALO_W;
-            int y = reflect1(y0 + hy - 1, H), x = reflect1(x0 + hx - 1, W);
-            if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
-            roff[k] = ((y * Ws + x) * a.cin + q * 4) * 4;
+            for (int k = 0; k < W4_RITEMS; ++k) {
+                const int idx = t + k * 256;
+                const int hp = min(idx >> 2, W4_HALO - 1), q = idx & 3;
+                const int hy = (hp * 241) >> 13, hx = hp - hy * W4_HALO_W;          // hp / 34 for hp < 400
+                int y = y0 + hy - 1, x = x0 + hx - 1;
+                if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
+                roff[k] = ((y * Ws + x) * a.cin + q * 4) * 4;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < W4_RITEMS; ++k) {
+                const int idx = t + k * 256;
+                const int hp = min(idx >> 2, W4_HALO - 1), q = idx & 3;
+                const int hy = hp / W4_HALO_W, hx = hp - hy * W4_HALO_W;
+                int y = reflect1(y0 + hy - 1, H), x = reflect1(x0 + hx - 1, W);
+                if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
+                roff[k] = ((y * Ws + x) * a.cin + q * 4) * 4;
+            }
         }
     };
     halo_offsets(tx0, ty0, gH, gW, gWs);
