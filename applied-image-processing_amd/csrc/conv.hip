@@ -87,18 +87,14 @@ __global__ void pack_conv_first_kernel(const float* __restrict__ w0, const float
     }
 }
 
-// last decoder conv (64->3, net.py:35): OIHW [3][64][3][3] -> [4 chunks][9 taps][4 quads][4 s][3 cout]
+// last decoder conv (64->3, net.py:35): OIHW [3][64][3][3] -> the A operand of conv_last_kernel's 32 MFMAs,
+// [j = 8 loads][lane][s = 4]: row n' = lane % 32 = tap * 3 + cout (rows 27..31 zero), input channel (2j + lane / 32) * 4 + s
 __global__ void pack_conv_last_kernel(const float* __restrict__ w, float* __restrict__ p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 4 * 9 * 4 * 4 * 3) return;
-    int r = i;
-    const int co = r % 3; r /= 3;
-    const int s = r & 3; r >>= 2;
-    const int q = r & 3; r >>= 2;
-    const int tap = r % 9; r /= 9;
-    const int c = r;
-    const int ci = c * KC + q * 4 + s;
-    p[i] = w[(co * 64 + ci) * 9 + tap];
+    if (i >= 8 * 64 * 4) return;
+    const int s = i & 3, l = (i >> 2) & 63, j = i >> 8;
+    const int np = l & 31, ci = (2 * j + (l >> 5)) * 4 + s;
+    p[i] = np < 27 ? w[((np % 3) * 64 + ci) * 9 + np / 3] : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -744,90 +740,105 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Last layer: 64 -> 3, no ReLU, NHWC in, NCHW image out.  N = 3 would waste 90 % of an MFMA tile and
-// fp32 MFMA has no rate advantage over the vector ALU, so this is a VALU kernel: one thread per
-// output pixel, inputs from the same LDS halo image as the MFMA kernel (conflict-free b128 reads),
-// weights wave-uniform (scalar loads).
+// Last layer: 64 -> 3, no ReLU, NHWC in, NCHW image out (net.py:33-35).  N = 3 would waste 90 % of an MFMA tile as a
+// convolution, so the layer runs as a GEMM over INPUT pixels followed by a shifted sum:
+//     T[p][tap * 3 + co] = sum_ci x[p][ci] * w[co][ci][tap]          (K = 64, 27 of 32 MFMA rows used)
+//     out[y][x][co]      = bias[co] + sum_tap T[(y + dy, x + dx)][tap * 3 + co]
+// Every input pixel of the reflect-padded 18 x 34 halo of a 16 x 32 tile goes global memory -> registers -> B operand once
+// (no input staging in LDS, no 9-fold operand re-read); the weights are the A operand, 32 registers loaded once; T meets in
+// LDS (28 floats per halo pixel) and each thread sums 9 x 3 values for its two pixels.  Per tile 20 x 32 MFMAs (4 waves x 5
+// groups of 32 halo pixels) = 5.4 GFLOP executed at 1024 x 1024 against 268 MB read: HBM-bound.
 // ---------------------------------------------------------------------------------------------
-// R output rows per thread (tile = 8 R rows x 32 pixels): the halo of a taller tile is a smaller share of what the workgroup
-// reads ((8R + 2) x 34 / (8R x 32): 1.33 for R = 1, 1.20 for R = 2), and every wave-uniform weight feeds R pixels.
-template <bool DBUF, int R>
-__global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                        const float* __restrict__ wpk, const float* __restrict__ bias,
-                                                        int H, int W, int tiles_x, int tiles_y) {
-    constexpr int TH = 8 * R, NTHR = 256, CIN = 64;
-    using Stager = HaloStager<SRC_DIRECT, TH, NTHR>;
-    constexpr int BUF = Stager::HALO * LSTR;
-    // DBUF: two LDS buffers, the next chunk's loads overlap this chunk's FMAs (2 blocks per CU);
-    // !DBUF: one buffer, several blocks per CU hide the load latency by occupancy instead
-    __shared__ __attribute__((aligned(16))) float smem[(DBUF ? 2 : 1) * BUF];
-    const int tid = threadIdx.x;
-    int bid = blockIdx.x;
-    const int tiles = tiles_x * tiles_y;
-    const int pt = bid % tiles;
-    const int img = bid / tiles;
-    const int tx0 = (pt % tiles_x) * TW, ty0 = (pt / tiles_x) * TH;
-    const rsrc_t src = make_rsrc(in + (size_t)img * H * W * CIN, (unsigned)H * W * CIN * 4u);
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
 
-    Stager st;
-    st.init(tid, ty0, tx0, H, W, H, W, CIN);
-    st.load(src, 0);
-    st.store(smem, tid);
+constexpr int CL_TH = 16, CL_HH = CL_TH + 2, CL_NPX = CL_HH * HW_;          // 612 halo pixels
+constexpr int CL_GRP = 5, CL_SLOTS = 4 * CL_GRP * 32;                        // 640 pixel slots (the last 28 repeat pixel 611)
+constexpr int CL_TSTR = 28;                                                   // floats per pixel record: 27 + 1 (16-byte rows)
+static_assert(CL_SLOTS >= CL_NPX, "conv_last: pixel groups must cover the halo");
+
+// CLD (diagnostic library only, ADAIN_CL_DIAG): 1 = no MFMAs (memory side alone: 60-63 us at 1024 x 1024), 2 = every load of a
+// group from one address (matrix side alone: 57 us), 4 = tiles in launch order (no XCD ranges: 68 us); product: 63-65 us
+template <int CLD>
+__global__ __launch_bounds__(256, 2) void conv_last_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                           int H, int W, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float T[CL_SLOTS * CL_TSTR];     // 71,680 B: two workgroups per CU
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 31, lh = lane >> 5;
+    const int tiles = tiles_x * tiles_y;
+    // the workgroups of one XCD (blockIdx % 8) take a contiguous range of the tile list: the halo rows and columns that
+    // neighbouring tiles share are re-read from that XCD's L2 (speed only)
+    int lid = blockIdx.x;
+    if (CLD != 4 && (gridDim.x & 7) == 0) lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
+    const int pt = lid % tiles, img = lid / tiles;
+    const int tx0 = (pt % tiles_x) * TW, ty0 = (pt / tiles_x) * CL_TH;
+    const rsrc_t src = make_rsrc(in + (size_t)img * H * W * 64, (unsigned)H * W * 256u);
+    const rsrc_t wsr = make_rsrc(wpk, 8 * 64 * 16);
+
+    f32x4 bx[3][8];
+    // group g: this lane's halo pixel, 8 x 16 bytes of its 256 (lane half lh takes the odd quads)
+    auto load_group = [&](auto G) {
+        constexpr int g = decltype(G)::value;
+        const int f = min((wave * CL_GRP + g) * 32 + px, CL_NPX - 1);
+        const int hy = (f * 241) >> 13, hx = f - hy * HW_;                   // f / 34 for f < 1024
+        const int y = reflect1(ty0 + hy - 1, H), x = reflect1(tx0 + hx - 1, W);
+        const int off = (y * W + x) * 256 + lh * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bx[g % 3][j] = buf_load4(src, off, CLD == 2 ? 0 : j * 32);
+    };
+    f32x4 wq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wq[j] = buf_load4(wsr, lane * 16, j * 1024);
+    __builtin_amdgcn_sched_barrier(0);       // weights and two pixel groups in flight before the first MFMA (hipcc sinks the loads otherwise)
+    load_group(std::integral_constant<int, 0>{});
+    load_group(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+
+    static_for<CL_GRP>([&](auto G) {
+        constexpr int g = decltype(G)::value;
+        if constexpr (g + 2 < CL_GRP) load_group(std::integral_constant<int, g + 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if constexpr (CLD == 1) acc[(j * 4 + s) & 15] += wq[j][s] * bx[g % 3][j][s];
+                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j][s], bx[g % 3][j][s], acc, 0, 0, 0);
+            }
+        // D[row n' = (r & 3) + 8 (r >> 2) + 4 lh][column = this lane's pixel]: four consecutive rows per b128
+        float* rec = T + ((wave * CL_GRP + g) * 32 + px) * CL_TSTR + lh * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < 3 || lh == 0) *(f32x4*)(rec + q * 8) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+    });
     __syncthreads();
 
-    const int py = tid >> 5, px = tid & 31;
-    // output channels 0 and 1 ride in one packed fp32 FMA (v_pk_fma_f32: the input value broadcast to both halves, the two
-    // weights a wave-uniform register pair), channel 2 in a plain one: two vector instructions per (input channel, tap) instead of
-    // three - the kernel's 1728 FMAs per pixel are a third of its time at the plain-FMA rate
-    using f32x2 = __attribute__((ext_vector_type(2))) float;
-    f32x2 acc01[R];
-    float acc2[R];
+    const int ox = tid & 31, oy = tid >> 5;
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
 #pragma unroll
-    for (int r = 0; r < R; ++r) { acc01[r] = f32x2{0.f, 0.f}; acc2[r] = 0.f; }
-    constexpr int NCH = CIN / KC;
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-        const float* sbuf = smem + (DBUF ? (c & 1) * BUF : 0) + (py * HW_ + px) * LSTR;
-        const bool more = c + 1 < NCH;
-        if (more) st.load(src, (c + 1) * KC * 4);
-        const float* __restrict__ wc = wpk + c * (9 * 4 * 12);
-#pragma unroll 1
-        for (int ty = 0; ty < 3; ++ty) {
-#pragma unroll 1
-            for (int tx = 0; tx < 3; ++tx) {
-                const float* sp = sbuf + (ty * HW_ + tx) * LSTR;
-                const float* __restrict__ w = wc + (ty * 3 + tx) * 48;
+    for (int r = 0; r < 2; ++r) {
+        const int yy = oy + 8 * r;
+        float o0 = b0, o1 = b1, o2 = b2;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v[R];
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int r = 0; r < R; ++r) v[r] = *(const f32x4*)(sp + r * 8 * HW_ * LSTR + q * 4);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const f32x2 w01 = {w[q * 12 + s * 3 + 0], w[q * 12 + s * 3 + 1]};
-                        const float w2 = w[q * 12 + s * 3 + 2];
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            acc01[r] = __builtin_elementwise_fma(f32x2{v[r][s], v[r][s]}, w01, acc01[r]);
-                            acc2[r] = fmaf(v[r][s], w2, acc2[r]);
-                        }
-                    }
-                }
+            for (int dx = 0; dx < 3; ++dx) {
+                const float* tp = T + ((yy + dy) * HW_ + ox + dx) * CL_TSTR + (dy * 3 + dx) * 3;
+                o0 += tp[0]; o1 += tp[1]; o2 += tp[2];
             }
-        }
-        if (!DBUF) __syncthreads();
-        if (more) st.store(smem + (DBUF ? ((c + 1) & 1) * BUF : 0), tid);
-        __syncthreads();
-    }
-    const int x = tx0 + px;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int y = ty0 + py + 8 * r;
+        const int y = ty0 + yy, x = tx0 + ox;
         if (y < H && x < W) {
             float* __restrict__ o = out + (size_t)img * 3 * H * W + (size_t)y * W + x;
-            o[0] = acc01[r][0] + bias[0];
-            o[(size_t)H * W] = acc01[r][1] + bias[1];
-            o[(size_t)2 * H * W] = acc2[r] + bias[2];
+            o[0] = o0;
+            o[(size_t)H * W] = o1;
+            o[(size_t)2 * H * W] = o2;
         }
     }
 }
@@ -850,7 +861,7 @@ int launch_pack_conv_first(const float* w0, const float* b0, const float* w1, co
 }
 
 int launch_pack_conv_last(const float* w, float* p, hipStream_t s) {
-    hipLaunchKernelGGL(pack_conv_last_kernel, dim3(7), dim3(256), 0, s, w, p);
+    hipLaunchKernelGGL(pack_conv_last_kernel, dim3(8), dim3(256), 0, s, w, p);
     return check_launch("pack_conv_last");
 }
 
@@ -986,17 +997,17 @@ int launch_conv_last(const float* in, float* out, const float* packed, const flo
                      hipStream_t s) {
     if (H < 2 || W < 2 || n < 1) { set_error("conv_last: H, W must be >= 2, got %dx%d", H, W); return -1; }
     if ((size_t)H * W * 256 >= 0x7fffffffULL) { set_error("conv_last: a 64-channel image of %dx%d reaches 2 GiB (32-bit buffer offsets)", H, W); return -1; }
-    const int tx = (W + 31) / 32, ty = (H + 7) / 8;
+    const int tx = (W + TW - 1) / TW, ty = (H + CL_TH - 1) / CL_TH;
     if ((long long)tx * ty * n > 0x7fffffffLL) { set_error("conv_last: bad grid"); return -1; }
-    // single-buffered: 78 us vs 107 us double-buffered at 1024x1024 (occupancy beats overlap for this HBM-bound kernel);
-    // ADAIN_LAST_ROWS = output rows per thread (1: 8-row tiles, 2: 16-row tiles)
-    static const int rows_env = tune_env("ADAIN_LAST_ROWS", 1);      // 16-row tiles measured slower (98 vs 80 us at 1024x1024: one workgroup fewer per CU)
-    if (rows_env == 2 && H > 8) {
-        const int ty2 = (H + 15) / 16;
-        hipLaunchKernelGGL((conv_last_kernel<false, 2>), dim3((unsigned)(tx * ty2 * n)), dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty2);
-    } else {
-        hipLaunchKernelGGL((conv_last_kernel<false, 1>), dim3((unsigned)(tx * ty * n)), dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
-    }
+    const dim3 grid((unsigned)(tx * ty * n));
+#ifdef ADAIN_DIAG
+    static const int cld = tune_env("ADAIN_CL_DIAG", 0);
+    if (cld == 1) hipLaunchKernelGGL(conv_last_kernel<1>, grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
+    else if (cld == 2) hipLaunchKernelGGL(conv_last_kernel<2>, grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
+    else if (cld == 4) hipLaunchKernelGGL(conv_last_kernel<4>, grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
+    else
+#endif
+    hipLaunchKernelGGL(conv_last_kernel<0>, grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
     return check_launch("conv_last");
 }
 

@@ -454,6 +454,19 @@ def test_edge_sizes_layouts_and_dtypes(rt, nets, weights):
         close(vgg(c.cuda()), O.encode(vgg_sd, c))
 
 
+@pytest.mark.parametrize("n,hc,wc", [(1, 2, 2), (1, 2, 5), (2, 3, 9), (1, 5, 4), (1, 9, 3), (1, 4, 8), (1, 33, 17)])
+def test_decoder_alone_vs_oracle(rt, weights, n, hc, wc):
+    """The decoder on its own (net.py:6-36): feature maps whose 8x outputs end inside, on and past the last layer's 16 x 32
+    tiles (one partial tile, several tiles across and down, a batch)."""
+    _, dec_sd = weights
+    feat = T(np.maximum(synth.uniform_sym(600 + hc * 40 + wc, (n, 512, hc, wc), 3.0), 0.0).astype(np.float32))   # relu4_1-like
+    with torch.no_grad():
+        ref = O.decode(dec_sd, feat)
+    out = rt.decode(rt.nchw_to_nhwc(feat.cuda()), rt.pack_decoder(dec_sd, torch.device("cuda", 0)))
+    assert tuple(out.shape) == (n, 3, 8 * hc, 8 * wc)
+    close(out, ref, 5e-4, 5e-4)
+
+
 def test_batched_depth_and_mask_broadcast_rules(rt, weights):
     """Batch extensions of the C ABI (style_n / pmap_n / mask_n in {1, n}) against per-frame reference calls."""
     from applied_image_processing_amd.engine import AdaINEngine
