@@ -123,6 +123,41 @@ def test_resize_area_known_answers():
     assert r[0].tolist() == [3, 17, 33, 47, 63, 77] and (r == r[0]).all()
 
 
+def _area_mean_f64(src, dsize):
+    """INTER_AREA's DEFINITION, computed independently of the tap tables: the mean of the piecewise-constant source over the
+    destination pixel's footprint [d * scale, (d + 1) * scale), clipped to the image, in float64 via separable overlap matrices."""
+    wo, ho = dsize
+
+    def overlap(ssize, dsz):
+        scale = ssize / dsz
+        m = np.zeros((dsz, ssize))
+        for d in range(dsz):
+            lo, hi = d * scale, min((d + 1) * scale, ssize)
+            for sx in range(int(np.floor(lo)), min(int(np.ceil(hi)), ssize)):
+                m[d, sx] = max(0.0, min(hi, sx + 1) - max(lo, sx))
+            m[d] /= m[d].sum()
+        return m
+
+    a = src.astype(np.float64)
+    my, mx = overlap(src.shape[0], ho), overlap(src.shape[1], wo)
+    return np.einsum("ys,sxc->yxc", my, np.einsum("xt,stc->sxc", mx, a))
+
+
+def test_resize_area_is_the_area_mean():
+    """The restated OpenCV tap tables against the footprint mean they implement (float32 accumulation and the dropped < 1e-3
+    partial cells may move a value by one level; never more)."""
+    rng = np.random.default_rng(7)
+    for (h, w), (wo, ho) in (((64, 96), (48, 32)), ((90, 120), (40, 30)), ((270, 480), (228, 128)), ((100, 160), (61, 37)),
+                             ((97, 131), (65, 48)), ((256, 456), (171, 96))):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = O.resize_area_u8(a, (wo, ho)).astype(np.int64)
+        want = _area_mean_f64(a, (wo, ho))
+        d = np.abs(got - want)
+        assert d.max() <= 0.5 + 2e-3, (h, w, wo, ho, d.max())        # rounding of the exact mean, up to float32 noise at ties
+        if (h / ho) == 2 and (w / wo) == 2:
+            assert np.array_equal(got, np.floor(want + 0.5).astype(np.int64))     # the 2 x 2 form rounds half up
+
+
 def test_case_e_localized_colour_transfer_host_path():
     """The localized pipeline's Reinhard l-alpha-beta / PCA / CDF colour transfer (Style_3DGS/localized_style_transfer.py:22-168)
     is host-side numpy in the reference and here; pinned to the reference's own outputs (make_golden.py case E, produced with
