@@ -123,6 +123,28 @@ def test_resize_area_known_answers():
     assert r[0].tolist() == [3, 17, 33, 47, 63, 77] and (r == r[0]).all()
 
 
+def test_warp_is_bilinear_reflect_at_quantised_coordinates():
+    """cv2.remap restatement (unpinned against OpenCV: no cv2 here) against scipy's float64 bilinear sampler with
+    BORDER_REFLECT-equivalent mode='reflect', evaluated at the map rounded to 1/32 pixel (OpenCV's INTER_BITS = 5): the 2^15
+    fixed-point weights are exact multiples of 1/1024, so the restatement must equal round-half-up of the exact value everywhere,
+    including maps that leave the frame by more than its size."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(3)
+    h, w = 37, 53
+    prev = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    flow = (rng.standard_normal((2, h, w)) * 3).astype(np.float32)
+    flow[:, :3, :] *= 5
+    flow[:, :, -3:] *= 5
+    flow[:, 10, 10] = (-130.3, 77.7)                          # far outside: several reflections
+    x, y = np.meshgrid(np.arange(w), np.arange(h))
+    qx = np.rint((x + flow[0]).astype(np.float32) * np.float32(32)).astype(np.int64) / 32.0
+    qy = np.rint((y + flow[1]).astype(np.float32) * np.float32(32)).astype(np.int64) / 32.0
+    want = np.stack([ndimage.map_coordinates(prev[..., c].astype(np.float64), [qy, qx], order=1, mode="reflect") for c in range(3)], -1)
+    assert (qx < 0).any() and (qx > w - 1).any() and (qy < 0).any() and (qy > h - 1).any()
+    assert np.array_equal(O.warp_u8(prev, flow).astype(np.int64), np.floor(want + 0.5).astype(np.int64))
+
+
 def _area_mean_f64(src, dsize):
     """INTER_AREA's DEFINITION, computed independently of the tap tables: the mean of the piecewise-constant source over the
     destination pixel's footprint [d * scale, (d + 1) * scale), clipped to the image, in float64 via separable overlap matrices."""
