@@ -31,7 +31,7 @@ static const Layer DEC[8] = {{512, 256, SRC_DIRECT, 0}, {256, 256, SRC_UP2X, 0},
                              {256, 128, SRC_DIRECT, 0}, {128, 128, SRC_UP2X, 0},   {128, 64, SRC_DIRECT, 0},  {64, 64, SRC_UP2X, 0}};
 
 static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
-constexpr size_t FIRST_W = 2 * 5 * 64 * 4, FIRST_B = 64, LAST_W = 8 * 64 * 4, LAST_B = 3;
+constexpr size_t FIRST_W = 2 * 14 * 64, FIRST_B = 64, LAST_W = 8 * 64 * 4, LAST_B = 3;
 
 // Which form of the generic 3x3 layers the encoder / decoder schedules run.  The product library always runs the Winograd
 // F(4,3) x F(2,3) kernels (FORM_WINO4); the diagnostic build (-DADAIN_DIAG) can select the others for A/B runs:

@@ -58,33 +58,33 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
 
 // conv0 (1x1, 3->3, net.py:39) folded into conv1_1 (3->64, net.py:41): a pointwise conv commutes
 // with reflection padding, so W'[o][c][t] = sum_c' W1[o][c'][t] W0[c'][c] and
-// b'[o] = b1[o] + sum_{c',t} W1[o][c'][t] b0[c'].  K index k = 4 tap + c over 10 taps x (r, g, b, 0): the fourth
-// "channel" and the tenth tap are zero padding, so that one b128 LDS read of an [r, g, b, 0] halo pixel is one tap's K-slice.
-// packed (A operand = weights): [2 cout tiles][5 groups][64 lanes][4] with tap = 2 g + h, c = s.
+// b'[o] = b1[o] + sum_{c',t} W1[o][c'][t] b0[c'].  K index e = 3 tap + c for e < 27, and e = 27 multiplies a constant 1: its
+// weight is the bias b'[o], so the kernel's epilogue adds nothing (K = 28 = 14 MFMAs of K 2).
+// packed (A operand = weights): [2 cout tiles][14 steps][64 lanes] with cout = 32 T + lane % 32, e = 2 step + lane / 32.
 __global__ void pack_conv_first_kernel(const float* __restrict__ w0, const float* __restrict__ b0,
                                        const float* __restrict__ w1, const float* __restrict__ b1,
                                        float* __restrict__ p, float* __restrict__ bias_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 2 * 5 * 64 * 4) {
-        int r = i;
-        const int s = r & 3; r >>= 2;
-        const int lane = r & 63; r >>= 6;
-        const int g = r % 5; r /= 5;
-        const int T = r;
-        const int j = lane & 31, h = lane >> 5;
-        const int o = T * 32 + j, tap = 2 * g + h, c = s;
-        float v = 0.f;
-        if (tap < 9 && c < 3) {
+    auto folded_bias = [&](int o) {
+        float b = b1[o];
+        for (int cp = 0; cp < 3; ++cp)
+            for (int t = 0; t < 9; ++t) b += w1[(o * 3 + cp) * 9 + t] * b0[cp];
+        return b;
+    };
+    if (i < 2 * 14 * 64) {
+        const int lane = i & 63, step = (i >> 6) % 14, T = i / (14 * 64);
+        const int o = T * 32 + (lane & 31), e = 2 * step + (lane >> 5);
+        float v;
+        if (e < 27) {
+            const int tap = e / 3, c = e % 3;
+            v = 0.f;
             for (int cp = 0; cp < 3; ++cp) v += w1[(o * 3 + cp) * 9 + tap] * w0[cp * 3 + c];
+        } else {
+            v = folded_bias(o);
         }
         p[i] = v;
     }
-    if (i < 64) {
-        float b = b1[i];
-        for (int cp = 0; cp < 3; ++cp)
-            for (int t = 0; t < 9; ++t) b += w1[(i * 3 + cp) * 9 + t] * b0[cp];
-        bias_out[i] = b;
-    }
+    if (i < 64) bias_out[i] = folded_bias(i);
 }
 
 // last decoder conv (64->3, net.py:35): OIHW [3][64][3][3] -> the A operand of conv_last_kernel's 32 MFMAs,
@@ -622,10 +622,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_persist_kernel(ConvAr
 // ---------------------------------------------------------------------------------------------
 // First layer: conv0 (1x1) folded into conv1_1 (3 -> 64), NCHW image in, NHWC out, ReLU.  HBM-bound: 12 B read and 256 B
 // written per pixel, so the kernel is built around its stores.
-//   * the reflect-padded 10 x 34 halo of an 8 x 32 pixel tile is staged once as [r, g, b, 0] pixels (at most 6 coalesced
+//   * the reflect-padded 10 x 34 halo of an 8 x 32 pixel tile is staged once as three colour planes (at most 6 coalesced
 //     scalar loads per thread instead of 27 gathered ones);
-//   * MFMA with A = weights, B = pixels: a tap's K-slice is ONE b128 LDS read of a halo pixel (K = 10 taps x 4, the padding
-//     multiplies zero weights), and a lane ends up holding 4 consecutive channels of one pixel;
+//   * MFMA with A = weights, B = pixels, K = 28: element e = 3 tap + colour is one dword LDS read (consecutive lanes read
+//     consecutive floats of a plane: no bank conflicts), e = 27 is a constant 1 against the folded bias; 14 MFMAs per
+//     32 x 32 output tile (round 2 started with K = 10 taps x [r, g, b, 0] = 40: 20 MFMAs); the weights (28 values per lane)
+//     stay in registers over the tile walk; a lane ends up holding 4 consecutive channels of one pixel;
 //   * each wave passes its two output rows through a private LDS row buffer so that every store instruction writes 1 KiB of
 //     contiguous NHWC memory (4 pixels x 64 channels, b128 per lane): 16 store instructions per wave and tile, where the
 //     accumulator layout itself would need 64 dword stores.
@@ -633,15 +635,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_persist_kernel(ConvAr
 constexpr int CF_OSTR = 68;      // floats per pixel of the row buffer: b128 writes of 8 consecutive pixels cover all 32 banks
 // Persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ...; the NEXT tile's halo pixels (at most 2 per thread) are loaded
 // into registers before the current tile's MFMAs and stores, so a workgroup's memory latency overlaps its own matrix work
-// (one tile per workgroup ran load -> 80 MFMAs per wave -> store strictly in sequence: 3.2 TB/s).
+// (one tile per workgroup ran load -> MFMAs -> store strictly in sequence: 3.2 TB/s).
 __global__ __launch_bounds__(256, 2) void conv_first_kernel(const float* __restrict__ img_nchw,
                                                             float* __restrict__ out, const float* __restrict__ wpk,
                                                             const float* __restrict__ bias, int H, int W, int tiles_x,
                                                             int tiles_y, int ntiles) {
     constexpr int HALO = 10 * 34;
-    // the halo image (5.4 KiB) and the four waves' row buffers (4 x 8.5 KiB) share the allocation: 34 KiB, 4 workgroups per CU
+    // the halo image (3 planes of 340 floats) and the four waves' row buffers (4 x 8.5 KiB) share the allocation: 34 KiB
     __shared__ __attribute__((aligned(16))) float smem[4 * 32 * CF_OSTR];
-    static_assert(HALO * 4 <= 4 * 32 * CF_OSTR, "LDS layout");
+    static_assert(HALO * 3 <= 4 * 32 * CF_OSTR, "LDS layout");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -671,11 +673,25 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(const float* __restr
     int t = blockIdx.x;
     if (t >= ntiles) return;
     halo_load(t);
+    // this lane's 2 x 14 weights (A operand; K index e = 2 g + lh) and the LDS offset of halo element e = (tap, channel): held
+    // in registers over the tile walk
+    float wf[2][14];
+    int koff[14];
+#pragma unroll
+    for (int g = 0; g < 14; ++g) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) wf[c][g] = wpk[(c * 14 + g) * 64 + lane];
+        const int e = min(2 * g + lh, 26), tap = e / 3;
+        koff[g] = (e % 3) * HALO + (tap / 3) * 34 + tap % 3;
+    }
     for (;;) {
         const int pt = t % tiles, img = t / tiles;
         const int tx0 = (pt % tiles_x) * 32, ty0 = (pt / tiles_x) * 8;
-        *(f32x4*)(smem + tid * 4) = h0;
-        if (second) *(f32x4*)(smem + (tid + 256) * 4) = h1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                    // planar [r | g | b][10][34]: the K reads below walk consecutive floats
+            smem[c * HALO + tid] = h0[c];
+            if (second) smem[c * HALO + tid + 256] = h1[c];
+        }
         __syncthreads();
         const int tn = t + gridDim.x;
         if (tn < ntiles) halo_load(tn);                  // in flight during this tile's MFMAs and stores
@@ -688,21 +704,17 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(const float* __restr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[c][m][r] = 0.f;
 #pragma unroll
-        for (int g = 0; g < 5; ++g) {
-            const int tap = min(2 * g + lh, 8);          // the tenth tap carries zero weights: any halo pixel will do
-            const int ty = tap / 3, tx = tap - ty * 3;
-            f32x4 wf[2], xf[2];
+        for (int g = 0; g < 14; ++g) {
+            float xf[2];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) wf[c] = *(const f32x4*)(wpk + ((c * 5 + g) * 64 + lane) * 4);      // 10 KiB in all: L1-resident
+            for (int m = 0; m < 2; ++m) {
+                xf[m] = smem[(wave * 2 + m) * 34 + li + koff[g]];
+                if (g == 13) xf[m] = lh ? 1.0f : xf[m];                       // e = 27: the bias row
+            }
 #pragma unroll
-            for (int m = 0; m < 2; ++m) xf[m] = *(const f32x4*)(smem + ((wave * 2 + m + ty) * 34 + li + tx) * 4);
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        acc[c][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[c][s], xf[m][s], acc[c][m], 0, 0, 0);
+                for (int m = 0; m < 2; ++m) acc[c][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[c][g], xf[m], acc[c][m], 0, 0, 0);
         }
         __syncthreads();                                 // every wave has read its halo pixels: the row buffers may overwrite them
 
@@ -717,10 +729,9 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(const float* __restr
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int ch = 32 * c + 8 * q + 4 * lh;
-                    const f32x4 b4 = *(const f32x4*)(bias + ch);
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[c][m][4 * q + e] + b4[e], 0.f);
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[c][m][4 * q + e], 0.f);      // the bias came in through K
                     *(f32x4*)(st + li * CF_OSTR + ch) = v;
                 }
             // the row buffer is private to the wave and LDS operations of one wave complete in order: no barrier
@@ -746,7 +757,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(const float* __restr
 //     out[y][x][co]      = bias[co] + sum_tap T[(y + dy, x + dx)][tap * 3 + co]
 // Every input pixel of the reflect-padded 18 x 34 halo of a 16 x 32 tile goes global memory -> registers -> B operand once
 // (no input staging in LDS, no 9-fold operand re-read); the weights are the A operand, 32 registers loaded once; T meets in
-// LDS (28 floats per halo pixel) and each thread sums 9 x 3 values for its two pixels.  Per tile 20 x 32 MFMAs (4 waves x 5
+// LDS (27 planes of 640 pixel slots) and each thread sums 9 x 3 values for its two pixels.  Per tile 20 x 32 MFMAs (4 waves x 5
 // groups of 32 halo pixels) = 5.4 GFLOP executed at 1024 x 1024 against 268 MB read: HBM-bound.
 // ---------------------------------------------------------------------------------------------
 template <int N, class F>
@@ -756,7 +767,6 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 constexpr int CL_TH = 16, CL_HH = CL_TH + 2, CL_NPX = CL_HH * HW_;          // 612 halo pixels
 constexpr int CL_GRP = 5, CL_SLOTS = 4 * CL_GRP * 32;                        // 640 pixel slots (the last 28 repeat pixel 611)
-constexpr int CL_TSTR = 28;                                                   // floats per pixel record: 27 + 1 (16-byte rows)
 static_assert(CL_SLOTS >= CL_NPX, "conv_last: pixel groups must cover the halo");
 
 // CLD (diagnostic library only, ADAIN_CL_DIAG): 1 = no MFMAs (memory side alone: 60-63 us at 1024 x 1024), 2 = every load of a
@@ -765,7 +775,7 @@ template <int CLD>
 __global__ __launch_bounds__(256, 2) void conv_last_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                            const float* __restrict__ wpk, const float* __restrict__ bias,
                                                            int H, int W, int tiles_x, int tiles_y) {
-    __shared__ __attribute__((aligned(16))) float T[CL_SLOTS * CL_TSTR];     // 71,680 B: two workgroups per CU
+    __shared__ float T[27 * CL_SLOTS];                                       // [n'][pixel slot], 69,120 B: two workgroups per CU
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 31, lh = lane >> 5;
@@ -812,11 +822,14 @@ __global__ __launch_bounds__(256, 2) void conv_last_kernel(const float* __restri
                 if constexpr (CLD == 1) acc[(j * 4 + s) & 15] += wq[j][s] * bx[g % 3][j][s];
                 else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j][s], bx[g % 3][j][s], acc, 0, 0, 0);
             }
-        // D[row n' = (r & 3) + 8 (r >> 2) + 4 lh][column = this lane's pixel]: four consecutive rows per b128
-        float* rec = T + ((wave * CL_GRP + g) * 32 + px) * CL_TSTR + lh * 4;
+        // D[row n' = (r & 3) + 8 (r >> 2) + 4 lh][column = this lane's pixel] -> plane n' of T: a store instruction writes 32
+        // consecutive floats per lane half, and the shifted sum below reads consecutive floats too (no bank conflicts either way)
+        float* rec = T + (lh * 4) * CL_SLOTS + (wave * CL_GRP + g) * 32 + px;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q < 3 || lh == 0) *(f32x4*)(rec + q * 8) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        for (int r = 0; r < 16; ++r) {
+            const int np = (r & 3) + 8 * (r >> 2);                            // + 4 lh
+            if (np + 4 < 27 || (np < 27 && lh == 0)) rec[np * CL_SLOTS] = acc[r];
+        }
     });
     __syncthreads();
 
@@ -830,8 +843,8 @@ __global__ __launch_bounds__(256, 2) void conv_last_kernel(const float* __restri
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const float* tp = T + ((yy + dy) * HW_ + ox + dx) * CL_TSTR + (dy * 3 + dx) * 3;
-                o0 += tp[0]; o1 += tp[1]; o2 += tp[2];
+                const float* tp = T + (dy * 3 + dx) * 3 * CL_SLOTS + (yy + dy) * HW_ + ox + dx;
+                o0 += tp[0]; o1 += tp[CL_SLOTS]; o2 += tp[2 * CL_SLOTS];
             }
         const int y = ty0 + yy, x = tx0 + ox;
         if (y < H && x < W) {
@@ -856,7 +869,7 @@ int launch_pack_conv3x3(const float* w, float* p, int cin, int cout, hipStream_t
 
 int launch_pack_conv_first(const float* w0, const float* b0, const float* w1, const float* b1, float* p,
                            float* bias_out, hipStream_t s) {
-    hipLaunchKernelGGL(pack_conv_first_kernel, dim3(10), dim3(256), 0, s, w0, b0, w1, b1, p, bias_out);
+    hipLaunchKernelGGL(pack_conv_first_kernel, dim3(7), dim3(256), 0, s, w0, b0, w1, b1, p, bias_out);
     return check_launch("pack_conv_first");
 }
 

@@ -467,6 +467,36 @@ def test_decoder_alone_vs_oracle(rt, weights, n, hc, wc):
     close(out, ref, 5e-4, 5e-4)
 
 
+def test_called_from_a_background_thread(rt, nets):
+    """The reference's callers run adain_inference on a background threading.Thread (GUI.py:131): a call from a thread
+    that never touched the GPU gives the main thread's result bit for bit, and an error raised there carries that thread's text."""
+    import threading
+    from applied_image_processing_amd.AdaIN import test as t
+
+    vgg, dec = nets
+    c, s = T(synth.image(301, 1, 40, 72)).cuda(), T(synth.image(302, 1, 64, 48)).cuda()
+    want = t.style_transfer_simple(vgg, dec, c, s, 0.6).cpu()
+    got, errs = {}, {}
+
+    def work(key):
+        try:
+            got[key] = t.style_transfer_simple(vgg, dec, c, s, 0.6).cpu()
+            try:
+                rt.conv3x3(torch.zeros(1, 8, 8, 60, device="cuda"), torch.zeros(8, device="cuda"), torch.zeros(64, device="cuda"), 64)
+            except rt.AdainHipError as e:
+                errs[key] = str(e)
+        except Exception as e:      # surfaced by the asserts below
+            errs[key] = f"unexpected: {e!r}"
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for th in threads:
+        th.start()
+        th.join()
+    for k in range(2):
+        assert torch.equal(got[k], want)
+        assert k in errs and not errs[k].startswith("unexpected") and "cin" in errs[k]
+
+
 def test_batched_depth_and_mask_broadcast_rules(rt, weights):
     """Batch extensions of the C ABI (style_n / pmap_n / mask_n in {1, n}) against per-frame reference calls."""
     from applied_image_processing_amd.engine import AdaINEngine
