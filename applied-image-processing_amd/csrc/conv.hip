@@ -636,7 +636,7 @@ constexpr int CF_OSTR = 68;      // floats per pixel of the row buffer: b128 wri
 // Persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ...; the NEXT tile's halo pixels (at most 2 per thread) are loaded
 // into registers before the current tile's MFMAs and stores, so a workgroup's memory latency overlaps its own matrix work
 // (one tile per workgroup ran load -> MFMAs -> store strictly in sequence: 3.2 TB/s).
-__global__ __launch_bounds__(256, 2) void conv_first_kernel(const float* __restrict__ img_nchw,
+__global__ __launch_bounds__(256, 3) void conv_first_kernel(const float* __restrict__ img_nchw,
                                                             float* __restrict__ out, const float* __restrict__ wpk,
                                                             const float* __restrict__ bias, int H, int W, int tiles_x,
                                                             int tiles_y, int ntiles) {
@@ -1001,7 +1001,12 @@ int launch_conv_first(const float* img, float* out, const float* packed, const f
     if (ntiles > 0x7fffffffLL) { set_error("conv_first: bad grid"); return -1; }
     const int cus = device_cu_count();
     if (cus <= 0) { set_error("conv_first: device query failed"); return -1; }
-    const long long grid = ntiles < 2LL * cus ? ntiles : 2LL * cus;        // 2 workgroups per CU walk the tiles
+    long long per_cu = 3;                                                  // 3 workgroups per CU walk the tiles (same box: 2: 85 us, 3: 80, 4: 90)
+#ifdef ADAIN_DIAG
+    static const int wgs_env = tune_env("ADAIN_CF_WGS", 3);
+    per_cu = wgs_env;
+#endif
+    const long long grid = ntiles < per_cu * cus ? ntiles : per_cu * cus;
     hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)grid), dim3(256), 0, s, img, out, packed, bias, H, W, tx, ty, (int)ntiles);
     return check_launch("conv_first");
 }
