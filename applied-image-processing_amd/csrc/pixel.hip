@@ -500,8 +500,8 @@ int launch_warp_blend_u8(const uint8_t* cur, const uint8_t* prev, const float* f
 //     accumulates S * alpha over the x taps in table order in float, rows are combined sum = beta * buf, then
 //     sum += beta * buf, and the result is saturate_cast<uchar> (round-half-even).  Evaluated here in exactly that order
 //     without contraction; the tables are recomputed per thread in double (a handful of IEEE divisions).
-// Upscaling (a scale < 1: OpenCV emulates INTER_AREA with its fixed-point bilinear path) is not built: the video caller only
-// ever shrinks or copies (stylised frames are >= the target resolution).  Unpinned against OpenCV itself (cv2 is absent).
+// An enlarged axis (a scale < 1) leaves this branch: resize_area_linear_u8_kernel below.  Unpinned against OpenCV itself (cv2 is
+// absent).
 struct AreaTaps { int s0, n; float a_first, a_mid, a_last; };      // taps s0 .. s0 + n - 1; weights: first, middle ones, last
 
 __device__ __forceinline__ AreaTaps area_taps(int d, int ssize, double scale) {
@@ -565,12 +565,40 @@ __global__ __launch_bounds__(256) void resize_area_u8_kernel(const uint8_t* __re
     }
 }
 
+// INTER_AREA with an ENLARGED axis: cv::resize leaves the true-area branch and runs its generic linear path in "area mode" on
+// uint8 (resize.cpp: the coefficient loop with area_mode, HResizeLinear<uchar, int, short, 2048>, VResizeLinear's fixed-point
+// combine).  Per output index: s = cvFloor(d * scale); f = (float)((d + 1) - (s + 1) * inv_scale), f <= 0 -> 0 else f - cvFloor(f);
+// along x an index at the last source column gets f = 0 (the xmax rule); weights saturate_cast<short>((1.f - f, f) * 2048).
+struct AreaLin { int s; int w0, w1; };
+__device__ __forceinline__ AreaLin area_linear(int d, int ssize, double inv_scale, double scale, bool clamp_last) {
+    int sx = (int)floor((double)d * scale);
+    float f = (float)((double)(d + 1) - (double)(sx + 1) * inv_scale);
+    f = f <= 0.f ? 0.f : f - floorf(f);
+    if (clamp_last && sx >= ssize - 1) { f = 0.f; sx = ssize - 1; }
+    AreaLin r;
+    r.s = sx;
+    r.w0 = __float2int_rn((1.f - f) * 2048.f);
+    r.w1 = __float2int_rn(f * 2048.f);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void resize_area_linear_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int hi,
+                                                                    int wi, int c, int ho, int wo, double inv_x, double inv_y) {
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= wo || dy >= ho) return;
+    const uint8_t* __restrict__ src = in + (size_t)blockIdx.z * hi * wi * c;
+    uint8_t* __restrict__ dst = out + ((size_t)blockIdx.z * ho * wo + (size_t)dy * wo + dx) * c;
+    const AreaLin ax = area_linear(dx, wi, inv_x, 1. / inv_x, true), ay = area_linear(dy, hi, inv_y, 1. / inv_y, false);
+    const int x0 = ax.s, x1 = min(ax.s + 1, wi - 1), y0 = min(ay.s, hi - 1), y1 = min(ay.s + 1, hi - 1);
+    for (int ch = 0; ch < c; ++ch) {
+        const int r0 = (int)src[((size_t)y0 * wi + x0) * c + ch] * ax.w0 + (int)src[((size_t)y0 * wi + x1) * c + ch] * ax.w1;
+        const int r1 = (int)src[((size_t)y1 * wi + x0) * c + ch] * ax.w0 + (int)src[((size_t)y1 * wi + x1) * c + ch] * ax.w1;
+        dst[ch] = (uint8_t)((((ay.w0 * (r0 >> 4)) >> 16) + ((ay.w1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
 int launch_resize_area_u8(const uint8_t* in, uint8_t* out, int n, int hi, int wi, int c, int ho, int wo, hipStream_t s) {
     if (n < 1 || hi < 1 || wi < 1 || c < 1 || ho < 1 || wo < 1) { set_error("resize_area_u8: bad shape"); return -1; }
-    if (ho > hi || wo > wi) {
-        set_error("resize_area_u8: %dx%d -> %dx%d enlarges an axis; only the true-area branch of cv2.INTER_AREA (shrink or copy) is built", hi, wi, ho, wo);
-        return -1;
-    }
     if ((size_t)hi * wi * c >= 0x7fffffffULL || n > 65535 || (ho + 3) / 4 > 65535) { set_error("resize_area_u8: frame or batch too large"); return -1; }
     if (ho == hi && wo == wi) {
         if (hipMemcpyAsync(out, in, (size_t)n * hi * wi * c, hipMemcpyDeviceToDevice, s) != hipSuccess) {
@@ -579,11 +607,15 @@ int launch_resize_area_u8(const uint8_t* in, uint8_t* out, int n, int hi, int wi
         }
         return 0;
     }
+    const dim3 g((wo + 63) / 64, (ho + 3) / 4, n), b(64, 4);
+    if (ho > hi || wo > wi) {       // an enlarged axis: the fixed-point linear path in area mode
+        hipLaunchKernelGGL(resize_area_linear_u8_kernel, g, b, 0, s, in, out, hi, wi, c, ho, wo, (double)wo / wi, (double)ho / hi);
+        return check_launch("resize_area_u8");
+    }
     // cv::resize: inv_scale = dsize / ssize (double), scale = 1. / inv_scale, iscale = saturate_cast<int>(scale) (= cvRound)
     const double scale_x = 1. / ((double)wo / wi), scale_y = 1. / ((double)ho / hi);
     const int isx = (int)nearbyint(scale_x), isy = (int)nearbyint(scale_y);
     const bool fast = fabs(scale_x - isx) < 2.220446049250313e-16 && fabs(scale_y - isy) < 2.220446049250313e-16;
-    const dim3 g((wo + 63) / 64, (ho + 3) / 4, n), b(64, 4);
     if (!fast) hipLaunchKernelGGL(resize_area_u8_kernel<0>, g, b, 0, s, in, out, hi, wi, c, ho, wo, scale_x, scale_y, 0, 0);
     else if (isx == 2 && isy == 2 && (c == 1 || c == 3 || c == 4))
         hipLaunchKernelGGL(resize_area_u8_kernel<2>, g, b, 0, s, in, out, hi, wi, c, ho, wo, scale_x, scale_y, isx, isy);

@@ -365,7 +365,8 @@ def warp_blend_u8(cur, prev, flow, alpha):
 
 def resize_area_u8(frames, dsize):
     """cv2.resize(frame, dsize, interpolation=cv2.INTER_AREA) on uint8 HWC frames: [h,w,c] or a batch [n,h,w,c];
-    ``dsize`` = (width, height) as in cv2 (reference video/utils.py:352-353).  Shrinking / same size only."""
+    ``dsize`` = (width, height) as in cv2 (reference video/utils.py:352-353): the true-area branch when both axes shrink
+    or stay, OpenCV's fixed-point linear emulation when one is enlarged."""
     frames = _dev(frames, "frames", torch.uint8)
     single = frames.dim() == 3
     if single:

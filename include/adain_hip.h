@@ -128,8 +128,9 @@ int adain_warp_blend_u8(const uint8_t* cur_u8, const uint8_t* prev_u8, const flo
 /* cv2.resize(frames_u8, (wo, ho), interpolation=cv2.INTER_AREA) of the same post-pass (reference video/utils.py:352-353) on
  * n HWC uint8 frames [n][hi][wi][c] -> [n][ho][wo][c].  The true-area branch of OpenCV's resize (both axes shrink or keep
  * their size): equal sizes copy; integer scales box-average in int with round-half-even ((a+b+c+d+2)>>2 for 2x2); other
- * scales use resizeArea_'s float tap tables in OpenCV's accumulation order.  Enlarging an axis returns ADAIN_EINVAL (OpenCV
- * switches to its bilinear emulation there; the video caller never enlarges). */
+ * scales use resizeArea_'s float tap tables in OpenCV's accumulation order.  With an axis enlarged OpenCV leaves that branch
+ * and so does this call: the 11-bit fixed-point linear pass with "area mode" coefficients (an integer enlargement replicates
+ * pixels). */
 int adain_resize_area_u8(const uint8_t* in_u8, uint8_t* out_u8, int n, int hi, int wi, int c, int ho, int wo,
                          adain_stream_t stream);
 

@@ -226,6 +226,47 @@ def _area_tab(ssize, dsize, scale):
     return tab
 
 
+def _area_linear_coeffs(ssize, dsize, clamp_last):
+    """cv::resize's coefficient loop for INTER_AREA outside the true-area branch (resize.cpp, `area_mode`): per output index
+    the left source index and the two 11-bit fixed-point weights.  sx = cvFloor(d * scale); f = (float)((d + 1) - (sx + 1) *
+    inv_scale), f <= 0 -> 0 else f - cvFloor(f); along x an index at the last source column gets f = 0 (the xmax rule);
+    weights = saturate_cast<short>((1.f - f, f) * 2048) = round-half-even."""
+    import math
+
+    import numpy as np
+
+    inv_scale = dsize / ssize
+    scale = 1.0 / inv_scale
+    idx, w0, w1 = [], [], []
+    for d in range(dsize):
+        sx = math.floor(d * scale)
+        f = np.float32((d + 1) - (sx + 1) * inv_scale)
+        f = np.float32(0) if f <= 0 else np.float32(f - np.float32(math.floor(f)))
+        if clamp_last and sx >= ssize - 1:
+            f, sx = np.float32(0), ssize - 1
+        idx.append(sx)
+        w0.append(int(np.rint((np.float32(1) - f) * np.float32(2048))))
+        w1.append(int(np.rint(f * np.float32(2048))))
+    return np.array(idx), np.array(w0, dtype=np.int64), np.array(w1, dtype=np.int64)
+
+
+def _resize_area_linear_u8(img, wo, ho):
+    """INTER_AREA with an enlarged axis = cv::resize's generic linear path with area-mode coefficients on uint8:
+    HResizeLinear (int row buffer = S[sx] * a0 + S[sx + 1] * a1, 2048 = one), source rows sy and min(sy + 1, H - 1),
+    VResizeLinear's fixed-point combine ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2."""
+    import numpy as np
+
+    hi, wi, c = img.shape
+    sx, a0, a1 = _area_linear_coeffs(wi, wo, True)
+    sy, b0, b1 = _area_linear_coeffs(hi, ho, False)
+    S = img.astype(np.int64)
+    sx1 = np.minimum(sx + 1, wi - 1)
+    rows = S[:, sx, :] * a0[None, :, None] + S[:, sx1, :] * a1[None, :, None]            # [hi, wo, c]
+    r0, r1 = np.minimum(sy, hi - 1), np.minimum(sy + 1, hi - 1)
+    out = (((b0[:, None, None] * (rows[r0] >> 4)) >> 16) + ((b1[:, None, None] * (rows[r1] >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
 def resize_area_u8(src, dsize):
     """cv2.resize(src, dsize, interpolation=cv2.INTER_AREA) for uint8 HWC (or HW) images, ``dsize`` = (width, height), as the
     video caller applies it to every stylised frame (reference video/utils.py:352-353).  cv2 is a third-party dependency
@@ -233,7 +274,8 @@ def resize_area_u8(src, dsize):
     of OpenCV 4.x's cv::resize (modules/imgproc/src/resize.cpp): same size -> copy; integer scales -> resizeAreaFast_
     (int box sum, saturate_cast<uchar>(sum * (1.f / area)) = round-half-even; (a+b+c+d+2)>>2 for 2x2 with 1/3/4 channels);
     other scales -> resizeArea_<uchar, float> (computeResizeAreaTab taps, float accumulation over x taps then rows, in
-    OpenCV's order, round-half-even).  Enlarging an axis is not restated (OpenCV emulates it with fixed-point bilinear).
+    OpenCV's order, round-half-even).  When an axis is ENLARGED (scale < 1 on either axis) cv::resize leaves the true-area
+    branch and emulates INTER_AREA with its 11-bit fixed-point bilinear pass in "area mode" (_resize_area_linear_u8 below).
     PARITY UNPINNED against OpenCV itself (no cv2 here to generate vectors); known answers in tests/test_oracle_golden.py."""
     import numpy as np
 
@@ -244,10 +286,11 @@ def resize_area_u8(src, dsize):
         img = img[:, :, None]
     hi, wi, c = img.shape
     wo, ho = int(dsize[0]), int(dsize[1])
-    if ho > hi or wo > wi:
-        raise ValueError("resize_area_u8: enlarging an axis is not the true-area branch")
     if (ho, wo) == (hi, wi):
         out = img.copy()
+        return out[:, :, 0] if squeeze else out
+    if ho > hi or wo > wi:
+        out = _resize_area_linear_u8(img, wo, ho)
         return out[:, :, 0] if squeeze else out
     scale_x, scale_y = 1.0 / (wo / wi), 1.0 / (ho / hi)          # cv::resize: scale = 1. / inv_scale, inv_scale = dsize / ssize
     isx, isy = int(np.rint(scale_x)), int(np.rint(scale_y))     # saturate_cast<int>(double) = cvRound

@@ -66,6 +66,11 @@ def nccl_world1():
     (90, 121, 4, (57, 31)),        # four channels, fractional
     (64, 64, 3, (1, 1)),           # everything into one pixel
     (1080, 1920, 3, (1280, 720)),  # 1080p -> 720p (scale 1.5)
+    (256, 456, 3, (512, 288)),     # both axes enlarged (fractional): OpenCV's fixed-point linear emulation
+    (64, 96, 3, (192, 128)),       # integer enlargement 2 x 2: replication
+    (256, 456, 3, (256, 288)),     # x shrinks, y grows: still the linear path
+    (90, 121, 4, (300, 31)),       # x grows, y shrinks, four channels
+    (37, 53, 1, (54, 37)),         # one channel, x grows by 1 pixel
 ])
 def test_resize_area_u8_bit_exact_vs_oracle(rt, case):
     hi, wi, c, dsize = case
@@ -83,8 +88,9 @@ def test_resize_area_u8_batch_and_errors(rt):
     got = rt.resize_area_u8(T(frames).cuda(), (30, 20)).cpu().numpy()
     for i in range(3):
         assert np.array_equal(got[i], O.resize_area_u8(frames[i], (30, 20)))
-    with pytest.raises(rt.AdainHipError, match="enlarges"):
-        rt.resize_area_u8(T(frames).cuda(), (100, 48))
+    up = rt.resize_area_u8(T(frames).cuda(), (100, 48)).cpu().numpy()           # an enlarged axis, batched
+    for i in range(3):
+        assert np.array_equal(up[i], O.resize_area_u8(frames[i], (100, 48)))
     with pytest.raises(rt.AdainHipError):
         rt.resize_area_u8(T(frames).float().cuda(), (30, 20))
 

@@ -180,6 +180,24 @@ def test_resize_area_is_the_area_mean():
             assert np.array_equal(got, np.floor(want + 0.5).astype(np.int64))     # the 2 x 2 form rounds half up
 
 
+def test_resize_area_enlarged_axis_known_answers():
+    """INTER_AREA with an enlarged axis (OpenCV's fixed-point linear emulation, unpinned like the rest): integer factors
+    replicate pixels, a fractional factor mixes only the two source pixels a destination pixel straddles, and every value stays
+    within rounding of the float64 footprint mean."""
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    assert np.array_equal(O.resize_area_u8(a, (14, 10)), np.repeat(np.repeat(a, 2, 0), 2, 1))
+    assert np.array_equal(O.resize_area_u8(a, (21, 5)), np.repeat(a, 3, 1))
+    # 7 -> 10 columns: destination 1 covers [0.7, 1.4) = 0.3 of source 0 and 0.4 of source 1 (f = 4/7): 95 * 3/7 + 217 * 4/7 = 164.7;
+    # destination 3 covers [2.1, 2.8), inside source 2: 15; worked through by hand for all ten
+    row = np.array([[95, 217, 15, 215, 248, 69, 205]], dtype=np.uint8)
+    assert O.resize_area_u8(row, (10, 1))[0].tolist() == [95, 165, 188, 15, 158, 224, 248, 95, 127, 205]
+    for (h, w), (wo, ho) in (((37, 53), (80, 50)), ((64, 96), (100, 64)), ((30, 40), (40, 45))):
+        b = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        d = np.abs(O.resize_area_u8(b, (wo, ho)).astype(np.float64) - _area_mean_f64(b, (wo, ho)))
+        assert d.max() <= 1.0, (h, w, wo, ho, d.max())            # 11-bit weights and two truncating shifts: at most one level
+
+
 def test_case_e_localized_colour_transfer_host_path():
     """The localized pipeline's Reinhard l-alpha-beta / PCA / CDF colour transfer (Style_3DGS/localized_style_transfer.py:22-168)
     is host-side numpy in the reference and here; pinned to the reference's own outputs (make_golden.py case E, produced with
