@@ -719,10 +719,12 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const float* __restr
         __syncthreads();                                 // every wave has read its halo pixels: the row buffers may overwrite them
 
         float* const st = smem + wave * (32 * CF_OSTR);
-        const rsrc_t dst = make_rsrc(out + (size_t)img * H * W * 64, (unsigned)((size_t)H * W * 256));
+        // the output descriptor starts at the tile's first row: offsets stay inside 8 rows, the image may be of any size
+        const size_t oleft = (size_t)(H - ty0) * W * 256;
+        const rsrc_t dst = make_rsrc(out + ((size_t)img * H + ty0) * W * 64, oleft < 0x7ffffff0ull ? (unsigned)oleft : 0x7ffffff0u);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const int y = ty0 + wave * 2 + m;
+            const int ry = wave * 2 + m, y = ty0 + ry;
             // lane (li, lh) holds channels 32 c + 8 q + 4 lh + (0..3) of pixel li in acc[c][m][4 q .. 4 q + 3]
 #pragma unroll
             for (int c = 0; c < 2; ++c)
@@ -740,7 +742,7 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const float* __restr
                 const int idx = k * 64 + lane, px = idx >> 4, q16 = idx & 15;
                 const f32x4 v = *(const f32x4*)(st + px * CF_OSTR + q16 * 4);
                 const int x = tx0 + px;
-                const int off = ((y * W + x) * 64 + q16 * 4) * 4;
+                const int off = ((ry * W + x) * 64 + q16 * 4) * 4;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, (y < H && x < W) ? off : 0x7fffffff, 0, 0);
             }
         }
@@ -786,7 +788,10 @@ __global__ __launch_bounds__(256, 2) void conv_last_kernel(const float* __restri
     if (CLD != 4 && (gridDim.x & 7) == 0) lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
     const int pt = lid % tiles, img = lid / tiles;
     const int tx0 = (pt % tiles_x) * TW, ty0 = (pt / tiles_x) * CL_TH;
-    const rsrc_t src = make_rsrc(in + (size_t)img * H * W * 64, (unsigned)H * W * 256u);
+    // the source descriptor starts at the first row the tile's halo can touch: offsets stay inside 18 rows
+    const int srow0 = max(ty0 - 1, 0);
+    const size_t sleft = (size_t)(H - srow0) * W * 256;
+    const rsrc_t src = make_rsrc(in + ((size_t)img * H + srow0) * W * 64, sleft < 0x7ffffff0ull ? (unsigned)sleft : 0x7ffffff0u);
     const rsrc_t wsr = make_rsrc(wpk, 8 * 64 * 16);
 
     f32x4 bx[3][8];
@@ -796,7 +801,7 @@ __global__ __launch_bounds__(256, 2) void conv_last_kernel(const float* __restri
         const int f = min((wave * CL_GRP + g) * 32 + px, CL_NPX - 1);
         const int hy = (f * 241) >> 13, hx = f - hy * HW_;                   // f / 34 for f < 1024
         const int y = reflect1(ty0 + hy - 1, H), x = reflect1(tx0 + hx - 1, W);
-        const int off = (y * W + x) * 256 + lh * 16;
+        const int off = ((y - srow0) * W + x) * 256 + lh * 16;
 #pragma unroll
         for (int j = 0; j < 8; ++j) bx[g % 3][j] = buf_load4(src, off, CLD == 2 ? 0 : j * 32);
     };
@@ -995,7 +1000,7 @@ int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s) 
 int launch_conv_first(const float* img, float* out, const float* packed, const float* bias, int n, int H, int W,
                       hipStream_t s) {
     if (H < 2 || W < 2 || n < 1) { set_error("conv_first: H, W must be >= 2, got %dx%d", H, W); return -1; }
-    if ((size_t)H * W * 256 >= 0x7fffffffULL) { set_error("conv_first: a 64-channel image of %dx%d reaches 2 GiB (32-bit buffer offsets)", H, W); return -1; }
+    if ((size_t)W * 256 * 8 >= 0x7ffffff0ULL) { set_error("conv_first: eight 64-channel rows of width %d reach 2 GiB", W); return -1; }
     const int tx = (W + 31) / 32, ty = (H + 7) / 8;
     const long long ntiles = (long long)tx * ty * n;
     if (ntiles > 0x7fffffffLL) { set_error("conv_first: bad grid"); return -1; }
@@ -1014,7 +1019,7 @@ int launch_conv_first(const float* img, float* out, const float* packed, const f
 int launch_conv_last(const float* in, float* out, const float* packed, const float* bias, int n, int H, int W,
                      hipStream_t s) {
     if (H < 2 || W < 2 || n < 1) { set_error("conv_last: H, W must be >= 2, got %dx%d", H, W); return -1; }
-    if ((size_t)H * W * 256 >= 0x7fffffffULL) { set_error("conv_last: a 64-channel image of %dx%d reaches 2 GiB (32-bit buffer offsets)", H, W); return -1; }
+    if ((size_t)W * 256 * 18 >= 0x7ffffff0ULL) { set_error("conv_last: eighteen 64-channel rows of width %d reach 2 GiB", W); return -1; }
     const int tx = (W + TW - 1) / TW, ty = (H + CL_TH - 1) / CL_TH;
     if ((long long)tx * ty * n > 0x7fffffffLL) { set_error("conv_last: bad grid"); return -1; }
     const dim3 grid((unsigned)(tx * ty * n));

@@ -116,7 +116,8 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
 // both through the same vgg) - so that the deep style-branch layers, too small to fill the chip on their own, ride in the
 // content launch's list.  A tile's geometry (H, W, pointers) comes from its segment's descriptor, re-read from the kernel
 // arguments at the two places that need it (the next tile's halo offsets, the epilogue's stores).
-template <int MODE, int DIAG = 0, bool PERSIST = false>
+// BIG: per-tile buffer descriptors (any image size); the default form keeps one descriptor per image (tensors below 2 GiB)
+template <int MODE, int DIAG = 0, bool PERSIST = false, bool BIG = false>
 __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(ConvArgs a, ConvSegs m, int items, int prio_mode) {
     __shared__ __attribute__((aligned(16))) float smem[DIAG == 2 ? W4_PEX + 8192 : (DIAG == 1 ? W4_PEX + 1024 : W4_PEX)];
     float* const Rs = smem;
@@ -198,11 +199,27 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     const int nst = a.cin / W4_KR;
     const int nch = a.cin / 8;
 
-    auto src_of = [&](const float* base, int Hs, int Ws, int im) {
-        const size_t per = (size_t)Hs * Ws * a.cin;
-        return make_rsrc(base + im * per, (unsigned)(per * 4u));
+    // BIG: per-tile buffer descriptors.  The source descriptor starts at the first source row a tile's halo can touch, the output
+    // descriptor (epilogue) at the tile's first output row, so every 32-bit offset stays inside a band of 10 source / 8 output
+    // rows and an image may be of any size; the default form keeps one descriptor per image (row 0), which caps a tensor at
+    // 2 GiB per image and costs 13 scalar registers less (same-box A/B: 0.4 % of the kernel's time).
+    auto src_row0 = [&](int y0) {
+        if constexpr (!BIG) return 0;
+        const int r = max(y0 - 1, 0);                  // reflection never reaches above this row (row -1 maps to row 1)
+        return MODE == SRC_UP2X ? r >> 1 : r;
     };
-    rsrc_t src = PERSIST ? src_of(m.s[seg].in, m.s[seg].Hs, m.s[seg].Ws, img) : src_of(a.in, a.Hs, a.Ws, img);
+    auto src_of = [&](const float* base, int Hs, int Ws, int im, int y0) {
+        if constexpr (!BIG) {
+            const size_t per = (size_t)Hs * Ws * a.cin;
+            return make_rsrc(base + im * per, (unsigned)(per * 4u));
+        } else {
+            const size_t row = (size_t)Ws * a.cin;
+            const int r0 = src_row0(y0);
+            const size_t left = (size_t)(Hs - r0) * row * 4;
+            return make_rsrc(base + ((size_t)im * Hs + r0) * row, left < 0x7ffffff0ull ? (unsigned)left : 0x7ffffff0u);
+        }
+    };
+    rsrc_t src = PERSIST ? src_of(m.s[seg].in, m.s[seg].Hs, m.s[seg].Ws, img, ty0) : src_of(a.in, a.Hs, a.Ws, img, ty0);
     const rsrc_t wsr = make_rsrc(a.wpk, (unsigned)a.cin * a.cout * 96u);
 
     // ---- raw halo staging: 340 pixels x 4 quads over 256 threads x 6 items ---------------------------------------------------
@@ -212,6 +229,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         // a tile whose 10 x 34 halo lies inside the image needs no reflection (92 % of the tiles at 1024 x 1024): the uniform
         // branch saves 14 of the 27 vector instructions per item, 84 per tile and wave
         const bool interior = PERSIST && y0 >= 1 && y0 + W4_HALO_H - 1 <= H && x0 >= 1 && x0 + W4_HALO_W - 1 <= W;
+        [[maybe_unused]] const int r0 = src_row0(y0);  // BIG: rows are counted from the tile's source descriptor
         if (interior) {
 #pragma unroll
             for (int k = 0; k < W4_RITEMS; ++k) {
@@ -220,6 +238,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 const int hy = (hp * 241) >> 13, hx = hp - hy * W4_HALO_W;          // hp / 34 for hp < 400
                 int y = y0 + hy - 1, x = x0 + hx - 1;
                 if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
+                if constexpr (BIG) y = MODE == SRC_UP2X ? y - r0 : hy;
                 roff[k] = ((y * Ws + x) * a.cin + q * 4) * 4;
             }
         } else {
@@ -230,6 +249,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 const int hy = hp / W4_HALO_W, hx = hp - hy * W4_HALO_W;
                 int y = reflect1(y0 + hy - 1, H), x = reflect1(x0 + hx - 1, W);
                 if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
+                if constexpr (BIG) y -= r0;
                 roff[k] = ((y * Ws + x) * a.cin + q * 4) * 4;
             }
         }
@@ -312,8 +332,15 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         const int eH = PERSIST ? m.s[seg].H : a.H, eW = PERSIST ? m.s[seg].W : a.W;
         float* const eout = PERSIST ? m.s[seg].out : a.out;
         const int Ho = a.pool_out ? (eH + 1) >> 1 : eH, Wo = a.pool_out ? (eW + 1) >> 1 : eW;
-        const rsrc_t dst = make_rsrc(eout + (size_t)img * Ho * Wo * a.cout, (unsigned)(Ho * Wo * a.cout) * 4u);
+        rsrc_t dst;
+        if constexpr (!BIG) {
+            dst = make_rsrc(eout + (size_t)img * Ho * Wo * a.cout, (unsigned)(Ho * Wo * a.cout) * 4u);
+        } else {                                                           // the tile's first output row is the descriptor's origin
+            const int orow0 = a.pool_out ? ty0 >> 1 : ty0;
+            dst = make_rsrc(eout + ((size_t)img * Ho + orow0) * Wo * a.cout, 0x7ffffff0u);      // stores are masked per lane, never range-checked
+        }
         const int oy = ty0 + 4 * (tl >> 4), ox = tx0 + 2 * (tl & 15);
+        const int ry = BIG ? 4 * (tl >> 4) : oy;                           // row counted from the descriptor's origin
         const int cbyte = (ct * 32 + 4 * q8) * 4;
         const bool colok0 = ox < eW, colok1 = ox + 1 < eW;
         const float relu_lo = a.relu ? 0.f : -__builtin_inff();
@@ -349,13 +376,14 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                     v = max4(v, y[2 * h2 + 1][0]);
                     if (colok1) v = max4(v, y[2 * h2 + 1][1]);
                 }
-                const int off = (((r0 >> 1) * Wo + (ox >> 1)) * a.cout) * 4 + cbyte;
+                const int off = BIG ? ((((ry >> 1) + h2) * Wo + (ox >> 1)) * a.cout) * 4 + cbyte
+                                    : (((r0 >> 1) * Wo + (ox >> 1)) * a.cout) * 4 + cbyte;
                 buf_store4(dst, v, (r0 < eH && colok0) ? off : 0x7fffffff);
             }
         } else {
 #pragma unroll
             for (int ap = 0; ap < 4; ++ap) {
-                const int off = (((oy + ap) * eW + ox) * a.cout) * 4 + cbyte;
+                const int off = (((ry + ap) * eW + ox) * a.cout) * 4 + cbyte;
                 const bool rowok = oy + ap < eH;
                 buf_store4(dst, y[ap][0], (rowok && colok0) ? off : 0x7fffffff);
                 buf_store4(dst, y[ap][1], (rowok && colok1) ? off + a.cout * 4 : 0x7fffffff);
@@ -582,7 +610,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 // branch splits the two chunks of a stage)
                 auto next_halo = [&]() {
                     halo_offsets(ntx0, nty0, m.s[nseg].H, m.s[nseg].W, m.s[nseg].Ws);
-                    src = src_of(m.s[nseg].in, m.s[nseg].Hs, m.s[nseg].Ws, nimg);
+                    src = src_of(m.s[nseg].in, m.s[nseg].Hs, m.s[nseg].Ws, nimg, nty0);
                 };
                 if (nst == 2) next_halo();
                 {   // stage 0, peeled: its first chunk starts the tile's accumulators (FIRST)
@@ -656,13 +684,19 @@ int launch_pack_wino4(const float* w, float* p, int cin, int cout, hipStream_t s
     return check_launch("pack_wino4");
 }
 
+// a per-image source or output tensor of 2 GiB or more needs the per-tile descriptors (BIG instantiations)
+static bool wino4_big(const ConvArgs& a) {
+    return (size_t)a.Hs * a.Ws * a.cin * 4 >= 0x7ffffff0ULL || (size_t)a.H * a.W * a.cout * 4 >= 0x7ffffff0ULL;
+}
+
 static int check_wino4_shape(const ConvArgs& a, int src_mode) {
     if (a.cin % W4_KR || a.cin < W4_KR) { set_error("conv3x3_wino4: cin %d not a multiple of 16", a.cin); return -1; }
     if (a.cout % 32) { set_error("conv3x3_wino4: cout %d not a multiple of 32", a.cout); return -1; }
     if (a.H < 2 || a.W < 2 || a.n < 1) { set_error("conv3x3_wino4: H, W must be >= 2, got %dx%d", a.H, a.W); return -1; }
-    if ((size_t)a.Hs * a.Ws * a.cin * 4 >= 0x7fffffffULL || (size_t)a.H * a.W * a.cout * 4 >= 0x7fffffffULL) {
-        set_error("conv3x3_wino4: per-image tensors must stay below 2 GiB (32-bit buffer offsets): %dx%d with %d / %d channels", a.H, a.W,
-                  a.cin, a.cout);
+    // 32-bit offsets address a band of 10 source / 8 output rows from a per-tile descriptor: the image itself may be of any size
+    if ((size_t)a.Ws * a.cin * 4 * 10 >= 0x7ffffff0ULL || (size_t)a.W * a.cout * 4 * 8 >= 0x7ffffff0ULL) {
+        set_error("conv3x3_wino4: a band of ten %d-channel source rows or eight %d-channel output rows of width %d reaches 2 GiB", a.cin,
+                  a.cout, a.W);
         return -1;
     }
     if ((size_t)a.cin * a.cout * 96 >= 0xffffffffULL) { set_error("conv3x3_wino4: packed weights must stay below 4 GiB"); return -1; }
@@ -719,6 +753,7 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     const bool persist_ok = a.cin <= persist_env && a.cin >= 2 * W4_KR && pgrid >= 8 && blocks >= 2 * pgrid;
     const bool persist = !a.dbg && persist_ok;
     const int items = (int)blocks;
+    const bool big = wino4_big(a);
     ConvSegs m{};
     m.count = 1;
     m.ctg = walk_group(a.cin, a.cout);
@@ -726,7 +761,9 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     m.s[0] = ConvSeg{a.in, a.out, a.n, a.H, a.W, a.Hs, a.Ws, a.tiles_x, a.tiles_y, 0};
     if (persist) {
         const dim3 pg((unsigned)pgrid);
-        if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true>), pg, dim3(256), 0, s, a, m, items, prio_env);
+        if (big && src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true, true>), pg, dim3(256), 0, s, a, m, items, prio_env);
+        else if (big) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, true, true>), pg, dim3(256), 0, s, a, m, items, prio_env);
+        else if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true>), pg, dim3(256), 0, s, a, m, items, prio_env);
         else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, true>), pg, dim3(256), 0, s, a, m, items, prio_env);
         return check_launch("conv3x3_wino4");
     }
@@ -749,7 +786,9 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
         return check_launch("conv3x3_wino4(diag)");
     }
 #endif
-    if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X>), g, dim3(256), 0, s, a, m, items, 0);
+    if (big && src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, false, true>), g, dim3(256), 0, s, a, m, items, 0);
+    else if (big) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, false, true>), g, dim3(256), 0, s, a, m, items, 0);
+    else if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X>), g, dim3(256), 0, s, a, m, items, 0);
     else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a, m, items, 0);
     return check_launch("conv3x3_wino4");
 }
@@ -761,12 +800,14 @@ int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int c
     m.ctg = walk_group(layer.cin, layer.cout);
     m.stagger = tune_env("ADAIN_W4_STAGGER", W4_STAGGER);
     long long total = 0;
+    bool big = false;
     ConvArgs a = layer;
     for (int i = 0; i < count; ++i) {
         a.in = segs[i].in; a.out = segs[i].out; a.n = segs[i].n;
         a.H = segs[i].H; a.W = segs[i].W; a.Hs = segs[i].Hs; a.Ws = segs[i].Ws;
         if (!a.in || !a.out) { set_error("conv3x3_wino4_multi: null pointer in segment %d", i); return -1; }
         if (check_wino4_shape(a, src_mode)) return -1;
+        big = big || wino4_big(a);
         m.s[i] = segs[i];
         m.s[i].tiles_x = (a.W + 31) / 32;
         m.s[i].tiles_y = (a.H + 7) / 8;
@@ -793,7 +834,9 @@ int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int c
     a.xcd_order = 1;
     a.dbg = nullptr;
     const dim3 pg((unsigned)pgrid);
-    if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true>), pg, dim3(256), 0, s, a, m, (int)total, prio_env);
+    if (big && src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true, true>), pg, dim3(256), 0, s, a, m, (int)total, prio_env);
+    else if (big) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, true, true>), pg, dim3(256), 0, s, a, m, (int)total, prio_env);
+    else if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true>), pg, dim3(256), 0, s, a, m, (int)total, prio_env);
     else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, true>), pg, dim3(256), 0, s, a, m, (int)total, prio_env);
     return check_launch("conv3x3_wino4(multi)");
 }

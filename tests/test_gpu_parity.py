@@ -564,14 +564,71 @@ def test_encode_multi_is_bitwise_the_separate_encodes(rt, weights, sizes):
         rt.encode_multi(xs + xs + xs, packed)                     # more than four segments
 
 
-def test_two_gib_limit_is_an_error_not_a_wraparound(rt, weights):
-    """Per-image activations use 32-bit buffer offsets: a 64-channel full-resolution layer of 2 GiB or more (content above
-    ~8.39 Mpixels) must be refused by the first layer already, before anything is launched with a wrapped offset."""
+def _conv_rows_cpu(x_nhwc_gpu, w, b, r0, r1, relu=True):
+    """F.conv2d of reflect-padded rows r0..r1-1 of a (huge) NHWC GPU tensor, from the rows it needs only."""
+    H = x_nhwc_gpu.shape[1]
+    lo, hi = max(r0 - 1, 0), min(r1 + 1, H)
+    crop = x_nhwc_gpu[:, lo:hi].cpu().permute(0, 3, 1, 2).contiguous()
+    crop = F.pad(crop, (1, 1, 1 if r0 == 0 else 0, 1 if r1 == H else 0), mode="reflect")
+    y = F.conv2d(crop, w, b)
+    return (F.relu(y) if relu else y).permute(0, 2, 3, 1)
+
+
+def test_conv_tensors_above_two_gib(rt):
+    """Per-image tensors of 2 GiB and more (DCI-4K frames: 4096 x 2200 x 64 channels = 2.31 GB) take the per-tile buffer
+    descriptors: rows at the top, around the 2 GiB mark (row 2048), and at the bottom against the CPU convolution of the rows
+    they need; direct source, fused 2x upsample (small source, huge output) and fused output pool (huge source)."""
+    H, W, C = 2200, 4096, 64
+    g = torch.Generator(device="cuda").manual_seed(77)
+    x = torch.rand((1, H, W, C), device="cuda", generator=g) - 0.3
+    assert x.numel() * 4 > 2 ** 31
+    w = T(synth.uniform_sym(78, (C, C, 3, 3), (6.0 / (9 * C)) ** 0.5))
+    b = T(synth.uniform_sym(79, (C,), 0.1))
+    wp = rt.conv3x3_wino_pack(w.cuda(), 5)
+    bands = ((0, 12), (2040, 2060), (H - 12, H))
+    out = rt.conv3x3_wino(x, wp, b.cuda(), C, rt.SRC_DIRECT, True, False, 5)
+    for r0, r1 in bands:
+        close(out[:, r0:r1], _conv_rows_cpu(x, w, b, r0, r1))
+    pooled = rt.conv3x3_wino(x, wp, b.cuda(), C, rt.SRC_DIRECT, True, True, 5)           # 1100 x 2048 x 64 out of the 2.31 GB source
+    for r0, r1 in bands:
+        ref = _conv_rows_cpu(x, w, b, r0, r1).permute(0, 3, 1, 2)
+        close(pooled[:, r0 // 2:r1 // 2], F.max_pool2d(ref, 2, 2).permute(0, 2, 3, 1))
+    del out, pooled
+    small = x[:, :H // 2, :W // 2].contiguous()                                            # 1100 x 2048 -> 2x upsampled inside the conv
+    up = rt.conv3x3_wino(small, wp, b.cuda(), C, rt.SRC_UP2X, True, False, 5)
+    assert tuple(up.shape) == (1, H, W, C)
+    for r0, r1 in bands:
+        lo_s, hi_s = max(r0 - 1, 0) // 2, (min(r1 + 1, H) + 1) // 2                       # source rows under upsampled rows r0-1 .. r1
+        u = small[:, lo_s:hi_s].repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)    # upsampled rows 2 lo_s .. 2 hi_s - 1
+        close(up[:, r0:r1], _conv_rows_cpu(u, w, b, r0 - 2 * lo_s, r1 - 2 * lo_s))
+
+
+def test_dci_4k_frame_bands_match_their_crops(rt, weights):
+    """A 4096 x 2208 frame (9 Mpixels: the 64-channel layers hold 2.32 GB) through encoder and decoder: feature / image rows
+    of the whole frame equal those of a 256-row band cut out of it, away from the cut (the bands start on multiples of 32 rows:
+    pooling grids and Winograd tiles line up at every scale, so only the tile walk differs) - around the 2 GiB mark (row 2048)
+    and at the bottom; a corner of the frame against the CPU oracle."""
     vgg_sd, dec_sd = weights
-    packed = rt.pack_encoder(vgg_sd, torch.device("cuda", 0))
-    x = torch.zeros((1, 3, 2160, 4096), device="cuda")           # 8.85 Mpixels: 64 channels = 2.27 GB
-    with pytest.raises(rt.AdainHipError, match="2 GiB"):
-        rt.encode(x, packed)
-    feat = torch.zeros((1, 270, 512, 512), device="cuda")        # decoder output 2160 x 4096
-    with pytest.raises(rt.AdainHipError, match="2 GiB"):
-        rt.decode(feat, rt.pack_decoder(dec_sd, torch.device("cuda", 0)))
+    enc, dec = rt.pack_encoder(vgg_sd, torch.device("cuda", 0)), rt.pack_decoder(dec_sd, torch.device("cuda", 0))
+    H, W = 2208, 4096
+    g = torch.Generator(device="cuda").manual_seed(91)
+    img = torch.rand((1, 3, H, W), device="cuda", generator=g)
+    full = rt.encode(img, enc)                                     # NHWC [1, 276, 512, 512]
+    assert tuple(full.shape) == (1, 276, 512, 512)
+    for a in (1920, H - 256):                                      # bands [a, a + 256): rows 2048.. cross 2 GiB in conv1_1 / conv1_2
+        assert a % 32 == 0
+        band = rt.encode(img[:, :, a:a + 256].contiguous(), enc)   # 32 feature rows
+        m = 12 if a + 256 < H else 0                               # feature rows clear of the cut (receptive field < 96 pixels)
+        close(full[:, a // 8 + 12:a // 8 + 32 - m], band[:, 12:32 - m], 1e-5, 1e-5)
+    feat = torch.rand((1, 276, 512, 512), device="cuda", generator=g) * 2.0
+    out = rt.decode(feat, dec)                                     # [1, 3, 2208, 4096]; dec8's output and conv_last's input: 2.32 GB
+    assert tuple(out.shape) == (1, 3, H, W)
+    for fa in (240, 276 - 32):
+        assert fa % 4 == 0
+        band = rt.decode(feat[:, fa:fa + 32].contiguous(), dec)    # 256 image rows
+        m = 64 if fa + 32 < 276 else 0
+        close(out[:, :, 8 * fa + 64:8 * (fa + 32) - m], band[:, :, 64:256 - m], 1e-5, 1e-5)
+    # a corner of the whole frame against the CPU oracle (encoder: rows 0..255, far from the bottom)
+    with torch.no_grad():
+        ref = O.encode(vgg_sd, img[:, :, :384, :256].cpu())
+    close(full[:, :24, :16].permute(0, 3, 1, 2), ref[:, :, :24, :16])
