@@ -139,7 +139,12 @@ __global__ __launch_bounds__(MS_THREADS) void mean_std_nchw_kernel(const float* 
 static int nhwc_blocks(int c, int hw) {
     const int rows = MS_THREADS / (c >> 2);
     int nblk = (hw + rows * 16 - 1) / (rows * 16);   // >= 16 row groups of work per block
-    if (nblk > 256) nblk = 256;
+    int cap = 256;
+#ifdef ADAIN_DIAG
+    static const int cap_env = tune_env("ADAIN_MS_BLOCKS", 256);
+    cap = cap_env;
+#endif
+    if (nblk > cap) nblk = cap;
     if (nblk < 1) nblk = 1;
     return nblk;
 }
