@@ -767,17 +767,17 @@ __device__ __forceinline__ void static_for(F&& f) {
     [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
 }
 
-constexpr int CL_TH = 16, CL_HH = CL_TH + 2, CL_NPX = CL_HH * HW_;          // 612 halo pixels
-constexpr int CL_GRP = 5, CL_SLOTS = 4 * CL_GRP * 32;                        // 640 pixel slots (the last 28 repeat pixel 611)
-static_assert(CL_SLOTS >= CL_NPX, "conv_last: pixel groups must cover the halo");
-
 // CLD (diagnostic library only, ADAIN_CL_DIAG): 1 = no MFMAs (memory side alone: 60-63 us at 1024 x 1024), 2 = every load of a
-// group from one address (matrix side alone: 57 us), 4 = tiles in launch order (no XCD ranges: 68 us); product: 63-65 us
-template <int CLD>
-__global__ __launch_bounds__(256, 2) void conv_last_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                           const float* __restrict__ wpk, const float* __restrict__ bias,
-                                                           int H, int W, int tiles_x, int tiles_y) {
-    __shared__ float T[27 * CL_SLOTS];                                       // [n'][pixel slot], 69,120 B: two workgroups per CU
+// group from one address (matrix side alone: 57 us), 4 = tiles in launch order (no XCD ranges: 68 us); product: 63-65 us.
+// TH = tile height: 16 (612 halo pixels = 20 groups of 32, 5 per wave; T = 69 KB: two workgroups per CU; the product) or 12
+// (476 pixels = 15 groups, the fourth wave takes 3; T = 52 KB: three workgroups per CU; diagnostic library, ADAIN_CL_TH=12:
+// 64.3-64.5 us against 64.5-65.5 on the same box - the third workgroup buys nothing here, unlike in conv_first).
+template <int CLD, int TH>
+__global__ __launch_bounds__(256, TH == 12 ? 3 : 2) void conv_last_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                          const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                                          int H, int W, int tiles_x, int tiles_y) {
+    constexpr int NPX = (TH + 2) * HW_, NGRP = (NPX + 31) / 32, GPW = (NGRP + 3) / 4, SLOTS = NGRP * 32;
+    __shared__ float T[27 * SLOTS];                                          // [n'][pixel slot]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 31, lh = lane >> 5;
@@ -787,18 +787,19 @@ __global__ __launch_bounds__(256, 2) void conv_last_kernel(const float* __restri
     int lid = blockIdx.x;
     if (CLD != 4 && (gridDim.x & 7) == 0) lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
     const int pt = lid % tiles, img = lid / tiles;
-    const int tx0 = (pt % tiles_x) * TW, ty0 = (pt / tiles_x) * CL_TH;
-    // the source descriptor starts at the first row the tile's halo can touch: offsets stay inside 18 rows
+    const int tx0 = (pt % tiles_x) * TW, ty0 = (pt / tiles_x) * TH;
+    // the source descriptor starts at the first row the tile's halo can touch: offsets stay inside TH + 2 rows
     const int srow0 = max(ty0 - 1, 0);
     const size_t sleft = (size_t)(H - srow0) * W * 256;
     const rsrc_t src = make_rsrc(in + ((size_t)img * H + srow0) * W * 64, sleft < 0x7ffffff0ull ? (unsigned)sleft : 0x7ffffff0u);
     const rsrc_t wsr = make_rsrc(wpk, 8 * 64 * 16);
 
     f32x4 bx[3][8];
-    // group g: this lane's halo pixel, 8 x 16 bytes of its 256 (lane half lh takes the odd quads)
+    // this wave's g-th group = group 4 g + wave of the tile: this lane's halo pixel, 8 x 16 bytes of its 256 (lane half lh takes
+    // the odd quads)
     auto load_group = [&](auto G) {
         constexpr int g = decltype(G)::value;
-        const int f = min((wave * CL_GRP + g) * 32 + px, CL_NPX - 1);
+        const int f = min((4 * g + wave) * 32 + px, NPX - 1);
         const int hy = (f * 241) >> 13, hx = f - hy * HW_;                   // f / 34 for f < 1024
         const int y = reflect1(ty0 + hy - 1, H), x = reflect1(tx0 + hx - 1, W);
         const int off = ((y - srow0) * W + x) * 256 + lh * 16;
@@ -813,27 +814,29 @@ __global__ __launch_bounds__(256, 2) void conv_last_kernel(const float* __restri
     load_group(std::integral_constant<int, 1>{});
     __builtin_amdgcn_sched_barrier(0);
 
-    static_for<CL_GRP>([&](auto G) {
+    static_for<GPW>([&](auto G) {
         constexpr int g = decltype(G)::value;
-        if constexpr (g + 2 < CL_GRP) load_group(std::integral_constant<int, g + 2>{});
+        if constexpr (g + 2 < GPW) load_group(std::integral_constant<int, g + 2>{});     // (a group past the tile's last repeats its last pixel)
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 acc;
+        if (4 * g + 3 < NGRP || 4 * g + wave < NGRP) {                        // wave-uniform, and only the last round can be short
+            f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if constexpr (CLD == 1) acc[(j * 4 + s) & 15] += wq[j][s] * bx[g % 3][j][s];
-                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j][s], bx[g % 3][j][s], acc, 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    if constexpr (CLD == 1) acc[(j * 4 + s) & 15] += wq[j][s] * bx[g % 3][j][s];
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j][s], bx[g % 3][j][s], acc, 0, 0, 0);
+                }
+            // D[row n' = (r & 3) + 8 (r >> 2) + 4 lh][column = this lane's pixel] -> plane n' of T: a store instruction writes 32
+            // consecutive floats per lane half, and the shifted sum below reads consecutive floats too (no bank conflicts either way)
+            float* rec = T + (lh * 4) * SLOTS + (4 * g + wave) * 32 + px;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int np = (r & 3) + 8 * (r >> 2);                        // + 4 lh
+                if (np + 4 < 27 || (np < 27 && lh == 0)) rec[np * SLOTS] = acc[r];
             }
-        // D[row n' = (r & 3) + 8 (r >> 2) + 4 lh][column = this lane's pixel] -> plane n' of T: a store instruction writes 32
-        // consecutive floats per lane half, and the shifted sum below reads consecutive floats too (no bank conflicts either way)
-        float* rec = T + (lh * 4) * CL_SLOTS + (wave * CL_GRP + g) * 32 + px;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int np = (r & 3) + 8 * (r >> 2);                            // + 4 lh
-            if (np + 4 < 27 || (np < 27 && lh == 0)) rec[np * CL_SLOTS] = acc[r];
         }
     });
     __syncthreads();
@@ -843,13 +846,14 @@ __global__ __launch_bounds__(256, 2) void conv_last_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int yy = oy + 8 * r;
+        if (yy >= TH) break;
         float o0 = b0, o1 = b1, o2 = b2;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const float* tp = T + (dy * 3 + dx) * 3 * CL_SLOTS + (yy + dy) * HW_ + ox + dx;
-                o0 += tp[0]; o1 += tp[CL_SLOTS]; o2 += tp[2 * CL_SLOTS];
+                const float* tp = T + (dy * 3 + dx) * 3 * SLOTS + (yy + dy) * HW_ + ox + dx;
+                o0 += tp[0]; o1 += tp[SLOTS]; o2 += tp[2 * SLOTS];
             }
         const int y = ty0 + yy, x = tx0 + ox;
         if (y < H && x < W) {
@@ -1020,17 +1024,23 @@ int launch_conv_last(const float* in, float* out, const float* packed, const flo
                      hipStream_t s) {
     if (H < 2 || W < 2 || n < 1) { set_error("conv_last: H, W must be >= 2, got %dx%d", H, W); return -1; }
     if ((size_t)W * 256 * 18 >= 0x7ffffff0ULL) { set_error("conv_last: eighteen 64-channel rows of width %d reach 2 GiB", W); return -1; }
-    const int tx = (W + TW - 1) / TW, ty = (H + CL_TH - 1) / CL_TH;
+    int th = 16;
+#ifdef ADAIN_DIAG
+    static const int th_env = tune_env("ADAIN_CL_TH", 16);
+    th = th_env == 12 ? 12 : 16;
+#endif
+    const int tx = (W + TW - 1) / TW, ty = (H + th - 1) / th;
     if ((long long)tx * ty * n > 0x7fffffffLL) { set_error("conv_last: bad grid"); return -1; }
     const dim3 grid((unsigned)(tx * ty * n));
 #ifdef ADAIN_DIAG
     static const int cld = tune_env("ADAIN_CL_DIAG", 0);
-    if (cld == 1) hipLaunchKernelGGL(conv_last_kernel<1>, grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
-    else if (cld == 2) hipLaunchKernelGGL(conv_last_kernel<2>, grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
-    else if (cld == 4) hipLaunchKernelGGL(conv_last_kernel<4>, grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
+    if (cld == 1) hipLaunchKernelGGL((conv_last_kernel<1, 16>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
+    else if (cld == 2) hipLaunchKernelGGL((conv_last_kernel<2, 16>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
+    else if (cld == 4) hipLaunchKernelGGL((conv_last_kernel<4, 16>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
+    else if (th == 12) hipLaunchKernelGGL((conv_last_kernel<0, 12>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
     else
 #endif
-    hipLaunchKernelGGL(conv_last_kernel<0>, grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
+    hipLaunchKernelGGL((conv_last_kernel<0, 16>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
     return check_launch("conv_last");
 }
 
