@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""One-off shape fuzz on the GPU box: random content / style sizes and batches through style_transfer_simple / style_transfer and
+the decoder alone, against the CPU oracle (relative L2 <= 1e-4, the parity bar).   python tools/fuzz_shapes.py [n_cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import applied_image_processing_amd.runtime as rt  # noqa: E402
+import applied_image_processing_amd.synth as synth  # noqa: E402
+from applied_image_processing_amd.AdaIN import net, test as t  # noqa: E402
+from oracle import adain_oracle as O  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+vgg_sd = synth.to_torch(synth.vgg_state_dict(0, full=True))
+dec_sd = synth.to_torch(synth.decoder_state_dict(0))
+net.vgg.load_state_dict(vgg_sd)
+net.decoder.load_state_dict(dec_sd)
+net.vgg.to("cuda:0")
+net.decoder.to("cuda:0")
+enc_sd = {k: v for k, v in vgg_sd.items()}
+worst = 0.0
+t0 = time.time()
+for case in range(n_cases):
+    n = int(rng.choice([1, 1, 1, 2, 3]))
+    h, w = int(rng.integers(9, 330)), int(rng.integers(9, 330))       # below 9 the reference fails too (ReflectionPad2d on a 1-row map)
+    hs, ws = int(rng.integers(9, 200)), int(rng.integers(9, 200))
+    if rng.random() < 0.15:
+        w = int(rng.integers(600, 1100))          # several 32-pixel tiles across, multi-XCD ranges
+    c = torch.from_numpy(synth.image(1000 + case, n, h, w))
+    s = torch.from_numpy(synth.image(5000 + case, n, hs, ws))
+    mode = case % 3
+    with torch.no_grad():
+        if mode == 0:
+            alpha = float(rng.random())
+            got = t.style_transfer_simple(net.vgg, net.decoder, c.cuda(), s.cuda(), alpha).cpu()
+            ref = O.style_transfer_simple(vgg_sd, dec_sd, c, s, alpha)
+        elif mode == 1 and n == 1:
+            d = torch.from_numpy(synth.smooth_depth(9000 + case, 2 * h + 3, w + 5))
+            got = t.style_transfer(net.vgg, net.decoder, c.cuda(), s.cuda(), d.cuda(), 1.0, 0.2, 15).cpu()
+            ref = O.style_transfer(vgg_sd, dec_sd, c, s, d, 1.0, 0.2, 15)
+        else:
+            hc, wc = max(2, h // 8), max(2, w // 8)
+            f = torch.from_numpy(np.maximum(synth.uniform_sym(7000 + case, (n, 512, hc, wc), 3.0), 0).astype(np.float32))
+            got = rt.decode(rt.nchw_to_nhwc(f.cuda()), rt.pack_decoder(dec_sd, torch.device("cuda", 0))).cpu()
+            ref = O.decode(dec_sd, f)
+    rel = float((got - ref).norm() / ref.norm())
+    worst = max(worst, rel)
+    flag = "" if rel <= 1e-4 and tuple(got.shape) == tuple(ref.shape) else "   <-- FAIL"
+    print(f"case {case:3d} mode {mode} n={n} content {h}x{w} style {hs}x{ws}: rel L2 {rel:.2e}{flag}", flush=True)
+    if flag:
+        sys.exit(1)
+print(f"{n_cases} cases, worst relative L2 {worst:.2e}, {time.time() - t0:.0f} s")
