@@ -83,6 +83,33 @@ def test_resize_area_u8_bit_exact_vs_oracle(rt, case):
     assert np.array_equal(got, want)
 
 
+def test_resize_area_u8_random_sizes(rt):
+    """Random source / destination sizes and channel counts: every branch (copy, 2 x 2, integer box, fractional taps, an
+    enlarged axis, mixed) bit for bit against the oracle."""
+    rng = np.random.default_rng(17)
+    seen = set()
+    for case in range(60):
+        hi, wi, c = int(rng.integers(1, 90)), int(rng.integers(1, 130)), int(rng.choice([1, 3, 3, 4]))
+        kind = case % 5
+        if kind == 0:
+            k = int(rng.integers(1, 4))
+            ho, wo = max(1, hi // k), max(1, wi // k)
+        elif kind == 1:
+            ho, wo = int(rng.integers(1, hi + 1)), int(rng.integers(1, wi + 1))
+        elif kind == 2:
+            ho, wo = int(rng.integers(hi, 3 * hi + 2)), int(rng.integers(wi, 3 * wi + 2))
+        elif kind == 3:
+            ho, wo = int(rng.integers(1, hi + 1)), int(rng.integers(wi, 2 * wi + 2))
+        else:
+            ho, wo = hi * int(rng.integers(1, 4)), wi * int(rng.integers(1, 4))
+        src = u8img(4000 + case, hi, wi, c)
+        got = rt.resize_area_u8(T(src).cuda(), (wo, ho)).cpu().numpy()
+        want = O.resize_area_u8(src, (wo, ho)).reshape(got.shape)
+        assert np.array_equal(got, want), (hi, wi, c, ho, wo, int(np.abs(got.astype(int) - want.astype(int)).max()))
+        seen.add((ho > hi or wo > wi, ho == hi and wo == wi))
+    assert len(seen) >= 3
+
+
 def test_resize_area_u8_batch_and_errors(rt):
     frames = np.stack([u8img(350 + i, 48, 80) for i in range(3)])
     got = rt.resize_area_u8(T(frames).cuda(), (30, 20)).cpu().numpy()
