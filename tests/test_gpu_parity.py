@@ -295,6 +295,31 @@ def test_pixel_kernels_vs_oracle(rt):
     assert torch.equal(rt.nhwc_to_nchw(rt.nchw_to_nhwc(f.cuda())).cpu(), f)
 
 
+def test_pixel_kernels_random_sizes(rt):
+    """Random plane counts and sizes (odd widths: every vector tail) through the pixel kernels of the mask composite, the
+    strength map and the quantiser."""
+    rng = np.random.default_rng(23)
+    for case in range(40):
+        n, c = int(rng.integers(1, 4)), int(rng.choice([1, 3, 3, 4]))
+        hi, wi, ho, wo = (int(v) for v in rng.integers(1, 150, 4))
+        x = T(synth.uniform_sym(300 + case, (n, c, hi, wi), 2.0))
+        # one ulp of a source coordinate near 150 (fused vs separate multiply-subtract) times the local gradient: a few 1e-5
+        close(rt.resize_bilinear(x.cuda(), (ho, wo)), F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=False), 1e-5, 5e-5)
+        assert torch.equal(rt.resize_nearest(x.cuda(), (ho, wo)).cpu(), F.interpolate(x, size=(ho, wo), mode="nearest"))
+        img = T(synth.uniform_sym(400 + case, (n, c, ho, wo), 0.8)) + 0.5
+        assert torch.equal(rt.quantize_u8(img.cuda()).cpu(), O.quantize_u8(img))
+        if c == 3:
+            content, sty = T(synth.image(500 + case, n, ho, wo)), T(synth.uniform_sym(600 + case, (n, 3, ho, wo), 1.0))
+            mc, mn = int(rng.choice([1, 3])), int(rng.choice([1, n]))
+            mask = T((synth.image(700 + case, mn, ho, wo, c=mc) > 0.5).astype(np.float32))
+            want = content * (1 - mask) + sty * mask
+            close(rt.mask_composite(content.cuda(), sty.cuda(), mask.cuda()), want, 1e-6, 1e-6)
+        h0, w0, hc, wc = int(rng.integers(2, 300)), int(rng.integers(2, 300)), int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        d = T(synth.smooth_depth(800 + case, h0, w0))
+        off, prom = float(rng.random() * 0.9), float(rng.random() * 30)
+        close(rt.strength_map(d.cuda(), hc, wc, off, prom), O.compute_stylization_strength_map(d, (hc, wc), off, prom), 1e-4, 2e-5)
+
+
 def test_video_warp_blend_vs_oracle(rt):
     h, w = 45, 61
     cur = (synth.image(81, 1, h, w)[0].transpose(1, 2, 0) * 255).astype(np.uint8)
