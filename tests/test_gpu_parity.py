@@ -83,6 +83,37 @@ def test_conv3x3_vs_oracle(rt, mode, shape):
     close(out2.permute(0, 3, 1, 2), F.conv2d(F.pad(src, (1, 1, 1, 1), mode="reflect"), w, b))
 
 
+def test_conv3x3_f43xf23_random_layers(rt):
+    """The product's 3x3 kernel (F(4,3) x F(2,3), form 5) on random layers: channel counts from 16 to 512, sizes from 2 x 2 to
+    150 x 200 (one-tile and persistent launches, ragged tiles), batches, direct / up-sampled source, output pool, ReLU on / off."""
+    rng = np.random.default_rng(31)
+    for case in range(36):
+        cin, cout = int(rng.choice([16, 32, 48, 64, 128, 256, 512])), int(rng.choice([32, 64, 96, 128, 256, 512]))
+        n, hs, ws = int(rng.integers(1, 4)), int(rng.integers(2, 150)), int(rng.integers(2, 200))
+        if cin * cout >= 128 * 256:
+            hs, ws = min(hs, 70), min(ws, 90)                                    # keeps the CPU reference quick
+        up, relu = bool(case % 3 == 1), bool(rng.random() < 0.7)
+        if up:
+            hs, ws = max(1, hs // 2), max(1, ws // 2)
+        pool = bool(case % 3 == 2)
+        x = T(synth.uniform_sym(2000 + case, (n, cin, hs, ws), 1.0))
+        w = T(synth.uniform_sym(2100 + case, (cout, cin, 3, 3), (6.0 / (9 * cin)) ** 0.5))
+        b = T(synth.uniform_sym(2200 + case, (cout,), 0.1))
+        src = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+        if min(src.shape[2:]) < 2:
+            continue
+        ref = F.conv2d(F.pad(src, (1, 1, 1, 1), mode="reflect"), w, b)
+        if relu:
+            ref = F.relu(ref)
+        if pool:
+            ref = F.max_pool2d(ref, 2, 2, 0, ceil_mode=True)
+        out = rt.conv3x3_wino(x.cuda().permute(0, 2, 3, 1).contiguous(), rt.conv3x3_wino_pack(w.cuda(), 5), b.cuda(), cout,
+                              rt.SRC_UP2X if up else rt.SRC_DIRECT, relu, pool, 5)
+        assert tuple(out.shape) == (n,) + tuple(ref.shape[2:]) + (cout,), (case, cin, cout, n, hs, ws, up, pool)
+        np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), rtol=RTOL, atol=ATOL,
+                                   err_msg=f"case {case}: {cin}->{cout} n={n} {hs}x{ws} up={up} pool={pool} relu={relu}")
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("shape", [(1, 64, 128, 19, 45), (2, 128, 128, 8, 33), (3, 64, 64, 70, 100)])
 def test_conv3x3_tile_variants_and_fused_output_pool(rt, variant, shape):
