@@ -565,6 +565,69 @@ __global__ __launch_bounds__(256) void resize_area_u8_kernel(const uint8_t* __re
     }
 }
 
+// The fractional form with the tap tables of a 64 x 16 output block computed once per block (80 table entries in LDS instead of
+// two per pixel: the tables are a dozen double-precision divisions each, which was nearly all of the kernel's time); a thread
+// owns four rows of one column.  Same arithmetic and accumulation order as resize_area_u8_kernel<0>.
+__global__ __launch_bounds__(256) void resize_area_tab_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int hi,
+                                                                 int wi, int c, int ho, int wo, double scale_x, double scale_y) {
+    __shared__ AreaTaps tx_s[64], ty_s[16];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int dx = blockIdx.x * 64 + threadIdx.x;
+    if (tid < 64) tx_s[tid] = area_taps(min(blockIdx.x * 64 + tid, wo - 1), wi, scale_x);
+    else if (tid < 80) ty_s[tid - 64] = area_taps(min(blockIdx.y * 16 + (tid - 64), ho - 1), hi, scale_y);
+    __syncthreads();
+    if (dx >= wo) return;
+    const AreaTaps tx = tx_s[threadIdx.x];
+    const uint8_t* __restrict__ src = in + (size_t)blockIdx.z * hi * wi * c;
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        const int ry = threadIdx.y + 4 * r, dy = blockIdx.y * 16 + ry;
+        if (dy >= ho) break;
+        const AreaTaps ty = ty_s[ry];
+        uint8_t* __restrict__ dst = out + ((size_t)blockIdx.z * ho * wo + (size_t)dy * wo + dx) * c;
+        for (int ch = 0; ch < c; ++ch) {
+            float sum = 0.f;
+            for (int j = 0; j < ty.n; ++j) {
+                const float beta = j == 0 ? ty.a_first : (j == ty.n - 1 ? ty.a_last : ty.a_mid);
+                const uint8_t* __restrict__ S = src + ((size_t)(ty.s0 + j) * wi + tx.s0) * c + ch;
+                float buf = 0.f;
+                for (int k = 0; k < tx.n; ++k) {
+                    const float alpha = k == 0 ? tx.a_first : (k == tx.n - 1 ? tx.a_last : tx.a_mid);
+                    buf = buf + (float)S[(size_t)k * c] * alpha;
+                }
+                sum = j == 0 ? beta * buf : sum + beta * buf;
+            }
+            dst[ch] = sat_u8_rne(sum);
+        }
+    }
+}
+
+// The 2 x 2 form on RGB frames whose width is a multiple of 8 (the common case: a 1080p / 720p / 456 x 256 frame halved): a
+// thread owns 4 output pixels = 8 source pixels of two rows, read as 2 x 2 dwordx3 (24 bytes are 4-byte aligned when the width
+// is a multiple of 4 pixels) and written as one dwordx3, instead of 48 byte loads and 12 byte stores.  Same integer arithmetic.
+__global__ __launch_bounds__(256) void resize_area2x2_rgb4_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int hi,
+                                                                  int wi, int ho, int wo) {
+    using u32x3 = __attribute__((ext_vector_type(3))) unsigned;
+    const int x4 = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;      // x4: group of 4 output pixels
+    if (x4 * 4 >= wo || dy >= ho) return;
+    const uint8_t* __restrict__ r0 = in + ((size_t)blockIdx.z * hi + 2 * dy) * wi * 3 + (size_t)x4 * 24;
+    const uint8_t* __restrict__ r1 = r0 + (size_t)wi * 3;
+    const u32x3 a0 = *(const u32x3*)r0, a1 = *(const u32x3*)(r0 + 12), b0 = *(const u32x3*)r1, b1 = *(const u32x3*)(r1 + 12);
+    const unsigned ra[6] = {a0[0], a0[1], a0[2], a1[0], a1[1], a1[2]}, rb[6] = {b0[0], b0[1], b0[2], b1[0], b1[1], b1[2]};
+    auto byte_of = [](const unsigned (&w)[6], int i) { return (w[i >> 2] >> (8 * (i & 3))) & 255u; };
+    unsigned o[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const int i0 = 6 * j + ch, i1 = i0 + 3;                 // source pixels 2j and 2j + 1
+            const unsigned v = (byte_of(ra, i0) + byte_of(ra, i1) + byte_of(rb, i0) + byte_of(rb, i1) + 2u) >> 2;
+            const int ob = 3 * j + ch;
+            o[ob >> 2] |= v << (8 * (ob & 3));
+        }
+    *(u32x3*)(out + (((size_t)blockIdx.z * ho + dy) * wo + (size_t)x4 * 4) * 3) = u32x3{o[0], o[1], o[2]};
+}
+
 // INTER_AREA with an ENLARGED axis: cv::resize leaves the true-area branch and runs its generic linear path in "area mode" on
 // uint8 (resize.cpp: the coefficient loop with area_mode, HResizeLinear<uchar, int, short, 2048>, VResizeLinear's fixed-point
 // combine).  Per output index: s = cvFloor(d * scale); f = (float)((d + 1) - (s + 1) * inv_scale), f <= 0 -> 0 else f - cvFloor(f);
@@ -616,7 +679,11 @@ int launch_resize_area_u8(const uint8_t* in, uint8_t* out, int n, int hi, int wi
     const double scale_x = 1. / ((double)wo / wi), scale_y = 1. / ((double)ho / hi);
     const int isx = (int)nearbyint(scale_x), isy = (int)nearbyint(scale_y);
     const bool fast = fabs(scale_x - isx) < 2.220446049250313e-16 && fabs(scale_y - isy) < 2.220446049250313e-16;
-    if (!fast) hipLaunchKernelGGL(resize_area_u8_kernel<0>, g, b, 0, s, in, out, hi, wi, c, ho, wo, scale_x, scale_y, 0, 0);
+    if (!fast && (ho + 15) / 16 <= 65535)
+        hipLaunchKernelGGL(resize_area_tab_u8_kernel, dim3((wo + 63) / 64, (ho + 15) / 16, n), b, 0, s, in, out, hi, wi, c, ho, wo, scale_x, scale_y);
+    else if (!fast) hipLaunchKernelGGL(resize_area_u8_kernel<0>, g, b, 0, s, in, out, hi, wi, c, ho, wo, scale_x, scale_y, 0, 0);
+    else if (isx == 2 && isy == 2 && c == 3 && wi % 8 == 0 && wo * 2 == wi && ((uintptr_t)in & 3) == 0 && ((uintptr_t)out & 3) == 0)
+        hipLaunchKernelGGL(resize_area2x2_rgb4_kernel, dim3((wo / 4 + 63) / 64, (ho + 3) / 4, n), b, 0, s, in, out, hi, wi, ho, wo);
     else if (isx == 2 && isy == 2 && (c == 1 || c == 3 || c == 4))
         hipLaunchKernelGGL(resize_area_u8_kernel<2>, g, b, 0, s, in, out, hi, wi, c, ho, wo, scale_x, scale_y, isx, isy);
     else hipLaunchKernelGGL(resize_area_u8_kernel<1>, g, b, 0, s, in, out, hi, wi, c, ho, wo, scale_x, scale_y, isx, isy);

@@ -57,7 +57,10 @@ def nccl_world1():
 # ---- INTER_AREA (video/utils.py:352-353) -----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", [
     (256, 456, 3, (256, 256)),     # the reference's own case: 456x256 stylised frame -> (256, 256): fractional x, y kept
-    (256, 456, 3, (228, 128)),     # 2 x 2 fast form
+    (256, 456, 3, (228, 128)),     # 2 x 2 fast form (vector kernel: width a multiple of 8)
+    (1080, 1920, 3, (960, 540)),   # 1080p halved
+    (100, 252, 3, (126, 50)),      # 2 x 2, width not a multiple of 8: the scalar form
+    (6, 8, 3, (4, 3)),             # 2 x 2, one group of four output pixels per row
     (256, 456, 3, (152, 128)),     # integer 3 x 2 box
     (256, 456, 3, (456, 256)),     # same size: copy
     (256, 456, 3, (100, 77)),      # fractional both axes
@@ -115,6 +118,9 @@ def test_resize_area_u8_batch_and_errors(rt):
     got = rt.resize_area_u8(T(frames).cuda(), (30, 20)).cpu().numpy()
     for i in range(3):
         assert np.array_equal(got[i], O.resize_area_u8(frames[i], (30, 20)))
+    half = rt.resize_area_u8(T(frames).cuda(), (40, 24)).cpu().numpy()           # 2 x 2 vector form, batched
+    for i in range(3):
+        assert np.array_equal(half[i], O.resize_area_u8(frames[i], (40, 24)))
     up = rt.resize_area_u8(T(frames).cuda(), (100, 48)).cpu().numpy()           # an enlarged axis, batched
     for i in range(3):
         assert np.array_equal(up[i], O.resize_area_u8(frames[i], (100, 48)))
