@@ -337,8 +337,8 @@ def measure_pixel_kernels(device, reps=10):
         ("mask_composite_kernel", px * 48, lambda i: rt.mask_composite(f32[i], f32b[i], msk[i])),
         ("resize_bilinear_kernel (same size)", px * 24, lambda i: rt.resize_bilinear(f32[i], (h, w))),
         ("resize_nearest_kernel (same size)", px * 24, lambda i: rt.resize_nearest(msk[i], (h, w))),
-        ("resize_area_u8_kernel (1080p -> 540x960, 2x2)", px * 3 * 5 // 4, lambda i: rt.resize_area_u8(u8[i], (w // 2, h // 2))),
-        ("resize_area_u8_kernel (1080p -> 720x1280, fractional)", px * 3 * 13 // 9, lambda i: rt.resize_area_u8(u8[i], (1280, 720))),
+        ("resize_area2x2_rgb4_kernel (1080p -> 540x960)", px * 3 * 5 // 4, lambda i: rt.resize_area_u8(u8[i], (w // 2, h // 2))),
+        ("resize_area_tab_u8_kernel (1080p -> 720x1280, fractional)", px * 3 * 13 // 9, lambda i: rt.resize_area_u8(u8[i], (1280, 720))),
         ("warp_blend_u8_kernel (one 1080p frame)", h * w * (9 + 8), lambda i: rt.warp_blend_u8(u8[i][0], u8[i][1], flow[i], 0.7)),
     ]
     out = []
