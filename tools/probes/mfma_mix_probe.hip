@@ -1,0 +1,108 @@
+// Microbenchmark: what do LDS reads, LDS writes and streaming vector-memory loads cost the fp32 matrix pipe beside plain vector
+// instructions?  Two waves per SIMD (two 256-thread workgroups per CU), every CU busy, v_mfma_f32_32x32x2_f32 on six accumulators
+// round-robin; per group of 8 MFMAs: NV v_fma_f32, NR ds_read_b128, NW ds_write_b128, NG buffer_load_dwordx4 (8 MB buffer,
+// L2 / Infinity-Cache resident), all independent of the MFMAs.  Loaded values are only "used" by an empty asm statement a
+// ring's length later (4 LDS reads; a memory load's slot one pass of 24 MFMAs later), so the loads cost their issue and their wait, not arithmetic.  Prints
+// chip-wide TFLOP/s by wall clock.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_mix_probe tools/probes/mfma_mix_probe.hip && /tmp/mfma_mix_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int;
+
+template <int NV, int NR, int NW, int NG>
+__global__ __launch_bounds__(256, 2) void k(float* out, const float* wbuf, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[18000];     // 70 KB: exactly two workgroups per CU
+    for (int i = threadIdx.x; i < 18000; i += 256) lds[i] = i * 0.001f;
+    __syncthreads();
+    f32x16 acc[6];
+    for (int i = 0; i < 6; ++i)
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = threadIdx.x * 0.01f + i;
+    f32x4 rd[4], gl[12];                                          // every index below is a compile-time constant
+    for (int i = 0; i < 4; ++i) rd[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 12; ++i) gl[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float a = threadIdx.x * 0.001f + 1.f, b = 0.5f + threadIdx.x * 0.002f, c = 1.0001f;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbuf), 0, 8u << 20, 0x00020000);
+    const int lane16 = (threadIdx.x & 255) * 20;                  // 80-byte stride: conflict-free b128
+    int goff = ((blockIdx.x * 256 + threadIdx.x) * 16) & ((8 << 20) - 1);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {                            // 3 groups of 8 MFMAs
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                acc[(g * 8 + h) % 6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[(g * 8 + h) % 6], 0, 0, 0);
+                // the group's other work spread over its 8 MFMAs
+#pragma unroll
+                for (int n = h; n < NV; n += 8) v[n & 7] = __builtin_fmaf(v[n & 7], c, b);
+#pragma unroll
+                for (int n = h; n < NR; n += 8) {
+                    asm volatile("" ::"v"(rd[(g * NR + n) & 3]));   // the value read four reads ago
+                    rd[(g * NR + n) & 3] = *(const f32x4*)(lds + lane16 + (n & 3) * 4);
+                }
+#pragma unroll
+                for (int n = h; n < NW; n += 8) *(f32x4*)(lds + lane16 + 8 + (n & 1) * 4) = rd[n & 3];
+#pragma unroll
+                for (int n = h; n < NG; n += 8) {
+                    asm volatile("" ::"v"(gl[g * NG + n]));         // the value this slot got one pass of 24 MFMAs ago
+                    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, goff, (g * 8 + n) * 4096, 0);
+                    gl[g * NG + n] = __builtin_bit_cast(f32x4, w);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        goff = (goff + 98304) & ((8 << 20) - 1);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 6; ++i)
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    for (int i = 0; i < 8; ++i) s += v[i];
+    for (int i = 0; i < 4; ++i) s += rd[i][0] + rd[i][3];
+    for (int i = 0; i < 12; ++i) s += gl[i][0] + gl[i][2];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int NV, int NR, int NW, int NG>
+static void run(const char* what) {
+    const int blocks = 512, iters = 400;
+    float *out, *wbuf;
+    hipMalloc(&out, blocks * 256 * sizeof(float));
+    hipMalloc(&wbuf, 8 << 20);
+    hipMemset(wbuf, 0, 8 << 20);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<NV, NR, NW, NG>), dim3(blocks), dim3(256), 0, 0, out, wbuf, iters);
+    hipEventRecord(e0, 0);
+    for (int rep = 0; rep < 5; ++rep) hipLaunchKernelGGL((k<NV, NR, NW, NG>), dim3(blocks), dim3(256), 0, 0, out, wbuf, iters);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = 5.0 * blocks * 4 * (double)iters * 24 * 4096;
+    printf("per 8 MFMAs: %2d v_fma  %d ds_read_b128  %d ds_write_b128  %d buffer_load_dwordx4 : %6.1f TFLOP/s   %s\n", NV, NR, NW, NG,
+           flops / (ms * 1e-3) / 1e12, what);
+    hipFree(out);
+    hipFree(wbuf);
+}
+
+int main() {
+    run<0, 0, 0, 0>("(warm-up)");
+    run<0, 0, 0, 0>("bare");
+    run<0, 2, 0, 0>("");
+    run<0, 4, 0, 0>("the kernel's patch reads: 12 per 24 MFMAs");
+    run<0, 8, 0, 0>("");
+    run<0, 0, 1, 0>("the kernel's staging writes: 6 per 48 MFMAs");
+    run<0, 0, 2, 0>("");
+    run<0, 0, 0, 2>("the weight stream: one b128 per 4 MFMAs");
+    run<0, 0, 0, 3>("weights + halo loads: 18 per 48 MFMAs");
+    run<0, 0, 0, 4>("");
+    run<25, 0, 0, 0>("the kernel's vector instructions: 152 per 48 MFMAs");
+    run<25, 4, 0, 0>("");
+    run<25, 4, 1, 0>("");
+    run<25, 4, 1, 3>("the whole main-loop mix");
+    run<13, 4, 1, 3>("half the vector instructions");
+    return 0;
+}
