@@ -64,6 +64,95 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const float* wbuf, int i
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// Design (c) of DESIGN.md section 8: eight-wave workgroups, one per CU; wave w < 4 transforms (NV vector instructions per 8 MFMAs)
+// and hands its fragments to wave w + 4 on the same SIMD through LDS (per 24 MFMAs 6 ds_write_b128 by the producer, 6
+// ds_read_b128 by the consumer), one workgroup barrier per 48 MFMAs; both waves carry the patch reads / weight loads of the mix.
+template <int NV>
+__global__ __launch_bounds__(512, 1) void kc(float* out, const float* wbuf, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[30000];     // 117 KB: one workgroup per CU
+    for (int i = threadIdx.x; i < 30000; i += 512) lds[i] = i * 0.001f;
+    __syncthreads();
+    const bool producer = threadIdx.x < 256;
+    f32x16 acc[6];
+    for (int i = 0; i < 6; ++i)
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = threadIdx.x * 0.01f + i;
+    f32x4 rd[4], gl[9], frag[6];
+    for (int i = 0; i < 4; ++i) rd[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 9; ++i) gl[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 6; ++i) frag[i] = f32x4{1.f, 2.f, 3.f, 4.f};
+    const float a = threadIdx.x * 0.001f + 1.f, b = 0.5f + threadIdx.x * 0.002f, c = 1.0001f;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbuf), 0, 8u << 20, 0x00020000);
+    const int lane16 = (threadIdx.x & 255) * 20;
+    float* hand = lds + 6000 + (threadIdx.x & 255) * 28;          // the pair's hand-off slots (6 fragments of 16 bytes, padded)
+    int goff = ((blockIdx.x * 512 + threadIdx.x) * 16) & ((8 << 20) - 1);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                   // 2 x 24 MFMAs, then the barrier
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    acc[(g * 8 + h) % 6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, frag[(g * 8 + h) % 6][h & 3], acc[(g * 8 + h) % 6], 0, 0, 0);
+                    if (producer) {
+#pragma unroll
+                        for (int n = h; n < NV; n += 8) v[n & 7] = __builtin_fmaf(v[n & 7], c, b);
+                        if (h < 2) *(f32x4*)(hand + (g * 2 + h) * 4) = f32x4{v[0], v[1], v[2], v[3]};      // 6 per 24 MFMAs
+                    } else if (h < 2) {
+                        frag[g * 2 + h] = *(const f32x4*)(hand + (g * 2 + h) * 4);
+                    }
+#pragma unroll
+                    for (int n = h; n < 4; n += 8) {
+                        asm volatile("" ::"v"(rd[(g * 4 + n) & 3]));
+                        rd[(g * 4 + n) & 3] = *(const f32x4*)(lds + lane16 + (n & 3) * 4);
+                    }
+#pragma unroll
+                    for (int n = h; n < 3; n += 8) {
+                        asm volatile("" ::"v"(gl[g * 3 + n]));
+                        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, goff, (g * 8 + n) * 4096, 0);
+                        gl[g * 3 + n] = __builtin_bit_cast(f32x4, w);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __syncthreads();
+        goff = (goff + 98304) & ((8 << 20) - 1);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 6; ++i)
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    for (int i = 0; i < 8; ++i) s += v[i];
+    for (int i = 0; i < 4; ++i) s += rd[i][0] + rd[i][3];
+    for (int i = 0; i < 9; ++i) s += gl[i][0] + gl[i][2];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int NV>
+static void run_pair(const char* what) {
+    const int blocks = 256, iters = 200;
+    float *out, *wbuf;
+    hipMalloc(&out, blocks * 512 * sizeof(float));
+    hipMalloc(&wbuf, 8 << 20);
+    hipMemset(wbuf, 0, 8 << 20);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((kc<NV>), dim3(blocks), dim3(512), 0, 0, out, wbuf, iters);
+    hipEventRecord(e0, 0);
+    for (int rep = 0; rep < 5; ++rep) hipLaunchKernelGGL((kc<NV>), dim3(blocks), dim3(512), 0, 0, out, wbuf, iters);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = 5.0 * blocks * 8 * (double)iters * 48 * 4096;
+    printf("producer / consumer pairs, %2d v_fma per 8 MFMAs on the producer only, barrier per 48 MFMAs : %6.1f TFLOP/s   %s\n", NV,
+           flops / (ms * 1e-3) / 1e12, what);
+    hipFree(out);
+    hipFree(wbuf);
+}
+
 template <int NV, int NR, int NW, int NG>
 static void run(const char* what) {
     const int blocks = 512, iters = 400;
@@ -104,5 +193,7 @@ int main() {
     run<25, 4, 1, 0>("");
     run<25, 4, 1, 3>("the whole main-loop mix");
     run<13, 4, 1, 3>("half the vector instructions");
+    run_pair<25>("design (c): one wave of a SIMD transforms for both");
+    run_pair<0>("the same without vector instructions");
     return 0;
 }
