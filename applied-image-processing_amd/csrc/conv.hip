@@ -794,7 +794,8 @@ __global__ __launch_bounds__(256, TH == 12 ? 3 : 2) void conv_last_kernel(const 
     const rsrc_t src = make_rsrc(in + ((size_t)img * H + srow0) * W * 64, sleft < 0x7ffffff0ull ? (unsigned)sleft : 0x7ffffff0u);
     const rsrc_t wsr = make_rsrc(wpk, 8 * 64 * 16);
 
-    f32x4 bx[3][8];
+    constexpr int PF = 2, RB = PF + 1;                            // pixel groups in flight ahead of the one being multiplied (3: 66.5 us, 2: 64.4-65.5)
+    f32x4 bx[RB][8];
     // this wave's g-th group = group 4 g + wave of the tile: this lane's halo pixel, 8 x 16 bytes of its 256 (lane half lh takes
     // the odd quads)
     auto load_group = [&](auto G) {
@@ -804,19 +805,18 @@ __global__ __launch_bounds__(256, TH == 12 ? 3 : 2) void conv_last_kernel(const 
         const int y = reflect1(ty0 + hy - 1, H), x = reflect1(tx0 + hx - 1, W);
         const int off = ((y - srow0) * W + x) * 256 + lh * 16;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bx[g % 3][j] = buf_load4(src, off, CLD == 2 ? 0 : j * 32);
+        for (int j = 0; j < 8; ++j) bx[g % RB][j] = buf_load4(src, off, CLD == 2 ? 0 : j * 32);
     };
     f32x4 wq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) wq[j] = buf_load4(wsr, lane * 16, j * 1024);
     __builtin_amdgcn_sched_barrier(0);       // weights and two pixel groups in flight before the first MFMA (hipcc sinks the loads otherwise)
-    load_group(std::integral_constant<int, 0>{});
-    load_group(std::integral_constant<int, 1>{});
+    static_for<PF>([&](auto G) { if constexpr (decltype(G)::value < GPW) load_group(G); });
     __builtin_amdgcn_sched_barrier(0);
 
     static_for<GPW>([&](auto G) {
         constexpr int g = decltype(G)::value;
-        if constexpr (g + 2 < GPW) load_group(std::integral_constant<int, g + 2>{});     // (a group past the tile's last repeats its last pixel)
+        if constexpr (g + PF < GPW) load_group(std::integral_constant<int, g + PF>{});   // (a group past the tile's last repeats its last pixel)
         __builtin_amdgcn_sched_barrier(0);
         if (4 * g + 3 < NGRP || 4 * g + wave < NGRP) {                        // wave-uniform, and only the last round can be short
             f32x16 acc;
@@ -826,8 +826,8 @@ __global__ __launch_bounds__(256, TH == 12 ? 3 : 2) void conv_last_kernel(const 
             for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    if constexpr (CLD == 1) acc[(j * 4 + s) & 15] += wq[j][s] * bx[g % 3][j][s];
-                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j][s], bx[g % 3][j][s], acc, 0, 0, 0);
+                    if constexpr (CLD == 1) acc[(j * 4 + s) & 15] += wq[j][s] * bx[g % RB][j][s];
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j][s], bx[g % RB][j][s], acc, 0, 0, 0);
                 }
             // D[row n' = (r & 3) + 8 (r >> 2) + 4 lh][column = this lane's pixel] -> plane n' of T: a store instruction writes 32
             // consecutive floats per lane half, and the shifted sum below reads consecutive floats too (no bank conflicts either way)
