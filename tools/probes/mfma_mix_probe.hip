@@ -11,10 +11,11 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int;
 
-template <int NV, int NR, int NW, int NG>
-__global__ __launch_bounds__(256, 2) void k(float* out, const float* wbuf, int iters) {
-    __shared__ __attribute__((aligned(16))) float lds[18000];     // 70 KB: exactly two workgroups per CU
-    for (int i = threadIdx.x; i < 18000; i += 256) lds[i] = i * 0.001f;
+template <int NV, int NR, int NW, int NG, int WPS = 2>
+__global__ __launch_bounds__(256, WPS) void k(float* out, const float* wbuf, int iters) {
+    constexpr int LDSF = WPS == 1 ? 30000 : 18000;                // 117 KB: one workgroup per CU; 70 KB: exactly two
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    for (int i = threadIdx.x; i < LDSF; i += 256) lds[i] = i * 0.001f;
     __syncthreads();
     f32x16 acc[6];
     for (int i = 0; i < 6; ++i)
@@ -153,9 +154,9 @@ static void run_pair(const char* what) {
     hipFree(wbuf);
 }
 
-template <int NV, int NR, int NW, int NG>
+template <int NV, int NR, int NW, int NG, int WPS = 2>
 static void run(const char* what) {
-    const int blocks = 512, iters = 400;
+    const int blocks = 256 * WPS, iters = 400;
     float *out, *wbuf;
     hipMalloc(&out, blocks * 256 * sizeof(float));
     hipMalloc(&wbuf, 8 << 20);
@@ -163,16 +164,16 @@ static void run(const char* what) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<NV, NR, NW, NG>), dim3(blocks), dim3(256), 0, 0, out, wbuf, iters);
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<NV, NR, NW, NG, WPS>), dim3(blocks), dim3(256), 0, 0, out, wbuf, iters);
     hipEventRecord(e0, 0);
-    for (int rep = 0; rep < 5; ++rep) hipLaunchKernelGGL((k<NV, NR, NW, NG>), dim3(blocks), dim3(256), 0, 0, out, wbuf, iters);
+    for (int rep = 0; rep < 5; ++rep) hipLaunchKernelGGL((k<NV, NR, NW, NG, WPS>), dim3(blocks), dim3(256), 0, 0, out, wbuf, iters);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const double flops = 5.0 * blocks * 4 * (double)iters * 24 * 4096;
-    printf("per 8 MFMAs: %2d v_fma  %d ds_read_b128  %d ds_write_b128  %d buffer_load_dwordx4 : %6.1f TFLOP/s   %s\n", NV, NR, NW, NG,
-           flops / (ms * 1e-3) / 1e12, what);
+    printf("%d wave(s)/SIMD, per 8 MFMAs: %2d v_fma  %d ds_read_b128  %d ds_write_b128  %d buffer_load_dwordx4 : %6.1f TFLOP/s   %s\n", WPS, NV, NR,
+           NW, NG, flops / (ms * 1e-3) / 1e12, what);
     hipFree(out);
     hipFree(wbuf);
 }
@@ -193,6 +194,12 @@ int main() {
     run<25, 4, 1, 0>("");
     run<25, 4, 1, 3>("the whole main-loop mix");
     run<13, 4, 1, 3>("half the vector instructions");
+    run<0, 0, 0, 0, 1>("bare, one wave per SIMD");
+    run<25, 0, 0, 0, 1>("");
+    run<25, 4, 1, 3, 1>("the whole mix on one wave per SIMD");
+    run<13, 0, 0, 0, 1>("");
+    run<13, 4, 1, 3, 1>("design (d): one wave per SIMD with two channel tiles = half the vector instructions per MFMA");
+    run<13, 8, 1, 6, 1>("(d) with twice the LDS reads and memory loads");
     run_pair<25>("design (c): one wave of a SIMD transforms for both");
     run_pair<0>("the same without vector instructions");
     return 0;
