@@ -568,8 +568,11 @@ __global__ __launch_bounds__(256) void resize_area_u8_kernel(const uint8_t* __re
 // The fractional form with the tap tables of a 64 x 16 output block computed once per block (80 table entries in LDS instead of
 // two per pixel: the tables are a dozen double-precision divisions each, which was nearly all of the kernel's time); a thread
 // owns four rows of one column.  Same arithmetic and accumulation order as resize_area_u8_kernel<0>.
+template <bool RGBW>
 __global__ __launch_bounds__(256) void resize_area_tab_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int hi,
-                                                                 int wi, int c, int ho, int wo, double scale_x, double scale_y) {
+                                                                 int wi, int c, int ho, int wo, double scale_x, double scale_y,
+                                                                 size_t total_bytes) {
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
     __shared__ AreaTaps tx_s[64], ty_s[16];
     const int tid = threadIdx.y * 64 + threadIdx.x;
     const int dx = blockIdx.x * 64 + threadIdx.x;
@@ -585,6 +588,48 @@ __global__ __launch_bounds__(256) void resize_area_tab_u8_kernel(const uint8_t* 
         if (dy >= ho) break;
         const AreaTaps ty = ty_s[ry];
         uint8_t* __restrict__ dst = out + ((size_t)blockIdx.z * ho * wo + (size_t)dy * wo + dx) * c;
+        if constexpr (RGBW) {
+            // RGB with at most 4 taps across (scale_x < 3): a row's taps are <= 12 consecutive bytes = ONE 16-byte load from the
+            // 4-byte-aligned address below them, shifted into place with v_alignbyte, instead of up to 12 byte loads; the
+            // arithmetic and its order are those of the loops below
+            float sum[3] = {0.f, 0.f, 0.f};
+            for (int j = 0; j < ty.n; ++j) {
+                const float beta = j == 0 ? ty.a_first : (j == ty.n - 1 ? ty.a_last : ty.a_mid);
+                const size_t byte0 = (((size_t)blockIdx.z * hi + ty.s0 + j) * wi + tx.s0) * 3, base = byte0 & ~(size_t)3;
+                unsigned w0, w1, w2;
+                if (base + 16 <= total_bytes) {
+                    const u32x4 w = *(const u32x4*)(in + base);
+                    const unsigned sh = (unsigned)(byte0 & 3);
+                    w0 = __builtin_amdgcn_alignbyte(w[1], w[0], sh);
+                    w1 = __builtin_amdgcn_alignbyte(w[2], w[1], sh);
+                    w2 = __builtin_amdgcn_alignbyte(w[3], w[2], sh);
+                } else {                                    // the last bytes of the last frame: byte by byte
+                    unsigned b[12];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) b[i] = i < tx.n * 3 ? in[byte0 + i] : 0u;
+                    w0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                    w1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+                    w2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+                }
+                const unsigned wd[3] = {w0, w1, w2};
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    float buf = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (k < tx.n) {
+                            const float alpha = k == 0 ? tx.a_first : (k == tx.n - 1 ? tx.a_last : tx.a_mid);
+                            const int bi = 3 * k + ch;
+                            buf = buf + (float)((wd[bi >> 2] >> (8 * (bi & 3))) & 255u) * alpha;
+                        }
+                    }
+                    sum[ch] = j == 0 ? beta * buf : sum[ch] + beta * buf;
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) dst[ch] = sat_u8_rne(sum[ch]);
+            continue;
+        }
         for (int ch = 0; ch < c; ++ch) {
             float sum = 0.f;
             for (int j = 0; j < ty.n; ++j) {
@@ -679,8 +724,13 @@ int launch_resize_area_u8(const uint8_t* in, uint8_t* out, int n, int hi, int wi
     const double scale_x = 1. / ((double)wo / wi), scale_y = 1. / ((double)ho / hi);
     const int isx = (int)nearbyint(scale_x), isy = (int)nearbyint(scale_y);
     const bool fast = fabs(scale_x - isx) < 2.220446049250313e-16 && fabs(scale_y - isy) < 2.220446049250313e-16;
-    if (!fast && (ho + 15) / 16 <= 65535)
-        hipLaunchKernelGGL(resize_area_tab_u8_kernel, dim3((wo + 63) / 64, (ho + 15) / 16, n), b, 0, s, in, out, hi, wi, c, ho, wo, scale_x, scale_y);
+    const size_t total_bytes = (size_t)n * hi * wi * c;
+    if (!fast && (ho + 15) / 16 <= 65535 && c == 3 && scale_x < 3.0 && ((uintptr_t)in & 3) == 0)        // at most 4 taps across
+        hipLaunchKernelGGL(resize_area_tab_u8_kernel<true>, dim3((wo + 63) / 64, (ho + 15) / 16, n), b, 0, s, in, out, hi, wi, c, ho, wo, scale_x,
+                           scale_y, total_bytes);
+    else if (!fast && (ho + 15) / 16 <= 65535)
+        hipLaunchKernelGGL(resize_area_tab_u8_kernel<false>, dim3((wo + 63) / 64, (ho + 15) / 16, n), b, 0, s, in, out, hi, wi, c, ho, wo, scale_x,
+                           scale_y, total_bytes);
     else if (!fast) hipLaunchKernelGGL(resize_area_u8_kernel<0>, g, b, 0, s, in, out, hi, wi, c, ho, wo, scale_x, scale_y, 0, 0);
     else if (isx == 2 && isy == 2 && c == 3 && wi % 8 == 0 && wo * 2 == wi && ((uintptr_t)in & 3) == 0 && ((uintptr_t)out & 3) == 0)
         hipLaunchKernelGGL(resize_area2x2_rgb4_kernel, dim3((wo / 4 + 63) / 64, (ho + 3) / 4, n), b, 0, s, in, out, hi, wi, ho, wo);
