@@ -1,0 +1,18 @@
+#!/bin/bash
+# FETCH_SIZE / WRITE_SIZE passes (separate runs, nothing else traced) of bench.py for one config -> gpurun_out/prof_<tag>_cfg<C>_{fetch,write}
+# Usage: tools/collect_traffic.sh <tag> <config> [<config> ...]
+set -o pipefail
+tag="$1"; shift
+root="${GRAFT_REPO_ROOT:-$PWD}"; out="$root/gpurun_out"
+mkdir -p "$out"; cd /tmp; export TMPDIR=/tmp
+for cfg in "$@"; do
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    name="cfg${cfg}_$( [ $ctr = FETCH_SIZE ] && echo fetch || echo write )"
+    echo "=== $name"
+    timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/prof_${tag}_$name" -- python3 "$root/bench.py" --config "$cfg" \
+        --no-cpu --no-secondary --steps 5 --warmup 1 > "$out/prof_${tag}_$name.log" 2> "$out/prof_${tag}_$name.err"
+    rc=$?; echo "=== $name rc=$rc"
+    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timed out: stopping"; exit 1; fi
+  done
+done
+find "$out" -path "*prof_${tag}_cfg*" -type f ! -name "*.csv" ! -name "*.log" ! -name "*.err" -delete
