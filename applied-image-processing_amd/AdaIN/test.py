@@ -73,6 +73,23 @@ def test_transform(size, crop):
 test_transform.__test__ = False  # not a pytest test
 
 
+def test_transform_u8(size, crop):
+    """``test_transform`` without its last step: the resized / cropped RGB image as uint8 HWC (numpy).  ToTensor (``/ 255``) then
+    runs on the device (``adain_encode_u8`` / ``adain_u8_to_f32``, bit-identical), so a frame crosses PCIe as 3 bytes per pixel.
+    Images that are not plain RGB (RGBA, L, ...) come back as the float tensor ``test_transform`` gives."""
+    def transform(img):
+        if size != 0:
+            img = img.resize(_resize_size(img.size[0], img.size[1], size), Image.BILINEAR)
+        if crop:
+            img = _center_crop(img, size)
+        return np.asarray(img, dtype=np.uint8) if img.mode == "RGB" else _to_tensor(img)
+
+    return transform
+
+
+test_transform_u8.__test__ = False
+
+
 def save_image(tensor, path):
     """torchvision.utils.save_image for one image (test.py:243-244): x*255 + 0.5, clamp, uint8, PIL save.
     The quantisation runs on the GPU (adain_quantize_u8)."""

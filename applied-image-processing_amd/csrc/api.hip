@@ -194,7 +194,8 @@ size_t adain_encode_multi_workspace_bytes(int count, const int* n, const int* h,
     return total;
 }
 
-int adain_encode_multi(int count, const float* const* images, float* const* feats, const int* n, const int* h, const int* w,
+// images[i]: NCHW float, or (u8 != 0) HWC uint8 converted as ToTensor does inside the first layer's kernel
+static int encode_impl(int count, const void* const* images, int u8, float* const* feats, const int* n, const int* h, const int* w,
                        const float* packed, void* workspace, size_t ws_bytes, void* const* ev, adain_stream_t stream) {
     if (count < 1 || count > MAX_CONV_SEGS) { set_error("encode: 1..%d image batches per call, got %d", MAX_CONV_SEGS, count); return ADAIN_EINVAL; }
     if (!images || !feats || !n || !h || !w || !packed || !workspace) { set_error("encode: null pointer"); return ADAIN_EINVAL; }
@@ -219,7 +220,7 @@ int adain_encode_multi(int count, const float* const* images, float* const* feat
         bufA[i] = base;
         bufB[i] = base + enc_buf_a(n[i], h[i], w[i]);
         base = bufB[i] + enc_buf_b(n[i], h[i], w[i]);
-        RET_IF(launch_conv_first(images[i], bufA[i], packed, packed + f.first_b, n[i], h[i], w[i], s));
+        RET_IF(launch_conv_first(images[i], u8, bufA[i], packed, packed + f.first_b, n[i], h[i], w[i], s));
         cur[i] = bufA[i];
         ch[i] = h[i]; cw[i] = w[i];
     }
@@ -256,10 +257,23 @@ int adain_encode_multi(int count, const float* const* images, float* const* feat
     return 0;
 }
 
+int adain_encode_multi(int count, const float* const* images, float* const* feats, const int* n, const int* h, const int* w,
+                       const float* packed, void* workspace, size_t ws_bytes, void* const* ev, adain_stream_t stream) {
+    return encode_impl(count, (const void* const*)images, 0, feats, n, h, w, packed, workspace, ws_bytes, ev, stream);
+}
+
 int adain_encode(const float* image, float* feat, const float* packed, void* workspace, size_t ws_bytes, int n, int h,
                  int w, void* const* ev, adain_stream_t stream) {
     if (!image || !feat) { set_error("encode: null pointer"); return ADAIN_EINVAL; }
-    return adain_encode_multi(1, &image, &feat, &n, &h, &w, packed, workspace, ws_bytes, ev, stream);
+    const void* img = image;
+    return encode_impl(1, &img, 0, &feat, &n, &h, &w, packed, workspace, ws_bytes, ev, stream);
+}
+
+int adain_encode_u8(const uint8_t* image, float* feat, const float* packed, void* workspace, size_t ws_bytes, int n, int h,
+                    int w, void* const* ev, adain_stream_t stream) {
+    if (!image || !feat) { set_error("encode: null pointer"); return ADAIN_EINVAL; }
+    const void* img = image;
+    return encode_impl(1, &img, 1, &feat, &n, &h, &w, packed, workspace, ws_bytes, ev, stream);
 }
 
 size_t adain_decode_workspace_bytes(int n, int hc, int wc) {
@@ -347,6 +361,10 @@ int adain_mask_composite(const float* content, const float* stylized, const floa
 int adain_quantize_u8(const float* in, uint8_t* out, int n, int c, int h, int w, adain_stream_t stream) {
     if (!in || !out) { set_error("quantize_u8: null pointer"); return ADAIN_EINVAL; }
     return launch_quantize_u8(in, out, n, c, h, w, (hipStream_t)stream);
+}
+int adain_u8_to_f32(const uint8_t* in, float* out, int n, int c, int h, int w, adain_stream_t stream) {
+    if (!in || !out) { set_error("u8_to_f32: null pointer"); return ADAIN_EINVAL; }
+    return launch_u8_to_f32(in, out, n, c, h, w, (hipStream_t)stream);
 }
 int adain_warp_blend_u8(const uint8_t* cur, const uint8_t* prev, const float* flow, uint8_t* out, int h, int w, int c, float alpha,
                         float one_minus_alpha, adain_stream_t stream) {

@@ -94,7 +94,8 @@ int launch_conv3x3_wino4(const ConvArgs& a, int src_mode, hipStream_t s);
 int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int count, int src_mode, hipStream_t s);
 // conv_wino3.hip
 int launch_conv3x3_wino3(const ConvArgs& a, int src_mode, hipStream_t s);
-int launch_conv_first(const float* img_nchw, float* out_nhwc, const float* packed, const float* bias, int n, int H,
+// img: NCHW float [n][3][H][W], or (u8 != 0) HWC uint8 [n][H][W][3] converted as ToTensor does (v / 255)
+int launch_conv_first(const void* img, int u8, float* out_nhwc, const float* packed, const float* bias, int n, int H,
                       int W, hipStream_t s);
 int launch_conv_last(const float* in_nhwc, float* out_nchw, const float* packed, const float* bias, int n, int H,
                      int W, hipStream_t s);
@@ -118,6 +119,7 @@ int launch_mask_composite(const float* content, const float* stylized, const flo
 int launch_warp_blend_u8(const uint8_t* cur, const uint8_t* prev, const float* flow, uint8_t* out, int h, int w, int c,
                          float alpha, float one_minus_alpha, hipStream_t s);
 int launch_quantize_u8(const float* in_nchw, uint8_t* out_nhwc, int n, int c, int h, int w, hipStream_t s);
+int launch_u8_to_f32(const uint8_t* in_nhwc, float* out_nchw, int n, int c, int h, int w, hipStream_t s);
 int launch_resize_area_u8(const uint8_t* in, uint8_t* out, int n, int hi, int wi, int c, int ho, int wo, hipStream_t s);
 int launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, hipStream_t s);

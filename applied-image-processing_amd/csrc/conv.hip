@@ -636,10 +636,16 @@ constexpr int CF_OSTR = 68;      // floats per pixel of the row buffer: b128 wri
 // Persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ...; the NEXT tile's halo pixels (at most 2 per thread) are loaded
 // into registers before the current tile's MFMAs and stores, so a workgroup's memory latency overlaps its own matrix work
 // (one tile per workgroup ran load -> MFMAs -> store strictly in sequence: 3.2 TB/s).
-__global__ __launch_bounds__(256, 3) void conv_first_kernel(const float* __restrict__ img_nchw,
+// U8: the image arrives as uint8 HWC [n][H][W][3] (a decoded frame as PIL / the job drivers hold it) and the kernel applies
+// torchvision's ToTensor itself, float(v) / 255 with a correctly rounded fp32 division (reference test.py:22, :203): the result is
+// bit-identical to encoding the float NCHW tensor, the frame crosses PCIe and HBM as 3 instead of 12 bytes per pixel.
+template <bool U8>
+__global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restrict__ img_any,
                                                             float* __restrict__ out, const float* __restrict__ wpk,
                                                             const float* __restrict__ bias, int H, int W, int tiles_x,
                                                             int tiles_y, int ntiles) {
+    const float* __restrict__ img_nchw = (const float*)img_any;
+    const uint8_t* __restrict__ img_u8 = (const uint8_t*)img_any;
     constexpr int HALO = 10 * 34;
     // the halo image (3 planes of 340 floats) and the four waves' row buffers (4 x 8.5 KiB) share the allocation: 34 KiB
     __shared__ __attribute__((aligned(16))) float smem[4 * 32 * CF_OSTR];
@@ -657,17 +663,19 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const float* __restr
     auto halo_load = [&](int t) {
         const int pt = t % tiles, img = t / tiles;
         const int tx0 = (pt % tiles_x) * 32, ty0 = (pt / tiles_x) * 8;
-        const float* __restrict__ src = img_nchw + (size_t)img * 3 * plane;
-        {
-            const int hy = tid / 34, hx = tid - hy * 34;
-            const float* __restrict__ q = src + (size_t)reflect1(ty0 + hy - 1, H) * W + reflect1(tx0 + hx - 1, W);
-            h0 = f32x4{q[0], q[plane], q[2 * plane], 0.f};
-        }
-        if (second) {
-            const int p = tid + 256, hy = p / 34, hx = p - hy * 34;
-            const float* __restrict__ q = src + (size_t)reflect1(ty0 + hy - 1, H) * W + reflect1(tx0 + hx - 1, W);
-            h1 = f32x4{q[0], q[plane], q[2 * plane], 0.f};
-        }
+        auto pixel = [&](int p) {
+            const int hy = p / 34, hx = p - hy * 34;
+            const size_t at = (size_t)reflect1(ty0 + hy - 1, H) * W + reflect1(tx0 + hx - 1, W);
+            if constexpr (U8) {      // raw bytes stay in the registers (as integer bit patterns) until the LDS store: the loads stay in flight
+                const uint8_t* __restrict__ q = img_u8 + ((size_t)img * plane + at) * 3;
+                return f32x4{__uint_as_float((unsigned)q[0]), __uint_as_float((unsigned)q[1]), __uint_as_float((unsigned)q[2]), 0.f};
+            } else {
+                const float* __restrict__ q = img_nchw + (size_t)img * 3 * plane + at;
+                return f32x4{q[0], q[plane], q[2 * plane], 0.f};
+            }
+        };
+        h0 = pixel(tid);
+        if (second) h1 = pixel(tid + 256);
     };
 
     int t = blockIdx.x;
@@ -689,8 +697,13 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const float* __restr
         const int tx0 = (pt % tiles_x) * 32, ty0 = (pt / tiles_x) * 8;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {                    // planar [r | g | b][10][34]: the K reads below walk consecutive floats
-            smem[c * HALO + tid] = h0[c];
-            if (second) smem[c * HALO + tid + 256] = h1[c];
+            if constexpr (U8) {                          // ToTensor: float(v) / 255, correctly rounded
+                smem[c * HALO + tid] = __fdiv_rn((float)__float_as_uint(h0[c]), 255.0f);
+                if (second) smem[c * HALO + tid + 256] = __fdiv_rn((float)__float_as_uint(h1[c]), 255.0f);
+            } else {
+                smem[c * HALO + tid] = h0[c];
+                if (second) smem[c * HALO + tid + 256] = h1[c];
+            }
         }
         __syncthreads();
         const int tn = t + gridDim.x;
@@ -1001,7 +1014,7 @@ int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s) 
     return -1;
 }
 
-int launch_conv_first(const float* img, float* out, const float* packed, const float* bias, int n, int H, int W,
+int launch_conv_first(const void* img, int u8, float* out, const float* packed, const float* bias, int n, int H, int W,
                       hipStream_t s) {
     if (H < 2 || W < 2 || n < 1) { set_error("conv_first: H, W must be >= 2, got %dx%d", H, W); return -1; }
     if ((size_t)W * 256 * 8 >= 0x7ffffff0ULL) { set_error("conv_first: eight 64-channel rows of width %d reach 2 GiB", W); return -1; }
@@ -1016,7 +1029,8 @@ int launch_conv_first(const float* img, float* out, const float* packed, const f
     per_cu = wgs_env;
 #endif
     const long long grid = ntiles < per_cu * cus ? ntiles : per_cu * cus;
-    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)grid), dim3(256), 0, s, img, out, packed, bias, H, W, tx, ty, (int)ntiles);
+    if (u8) hipLaunchKernelGGL(conv_first_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, img, out, packed, bias, H, W, tx, ty, (int)ntiles);
+    else hipLaunchKernelGGL(conv_first_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, img, out, packed, bias, H, W, tx, ty, (int)ntiles);
     return check_launch("conv_first");
 }
 

@@ -343,6 +343,43 @@ int launch_quantize_u8(const float* in, uint8_t* out, int n, int c, int h, int w
     return check_launch("quantize_u8");
 }
 
+// torchvision ToTensor on the device (reference test.py:22 via :203-204): NHWC u8 [n][hw][c] -> NCHW float [n][c][hw], float(v) / 255
+// with a correctly rounded division, i.e. bit for bit what `tensor.float() / 255` gives on the host.  The job drivers upload
+// frames as uint8 (3 bytes per pixel across PCIe instead of 12) and convert here (or inside conv_first_kernel<true>).
+// c == 3, hw % 4 == 0: a thread owns 4 pixels = one 96-bit load -> three b128 plane stores; blockIdx.y = image
+__global__ __launch_bounds__(256) void u8_to_f32_rgb4_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int hw) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q * 4 >= hw) return;
+    using u32x3 = __attribute__((ext_vector_type(3))) unsigned;
+    const u32x3 w = *(const u32x3*)(in + ((size_t)blockIdx.y * hw + q * 4) * 3);
+    f32x4 pl[3];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) pl[k % 3][k / 3] = __fdiv_rn((float)((w[k >> 2] >> (8 * (k & 3))) & 255u), 255.0f);
+    float* __restrict__ p = out + (size_t)blockIdx.y * 3 * hw + q * 4;
+    *(f32x4*)p = pl[0];
+    *(f32x4*)(p + hw) = pl[1];
+    *(f32x4*)(p + 2 * (size_t)hw) = pl[2];
+}
+
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int c, int hw) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= hw) return;
+    const uint8_t* __restrict__ p = in + ((size_t)blockIdx.y * hw + pix) * c;
+    float* __restrict__ o = out + (size_t)blockIdx.y * c * hw + pix;
+    for (int ch = 0; ch < c; ++ch) o[(size_t)ch * hw] = __fdiv_rn((float)p[ch], 255.0f);
+}
+
+int launch_u8_to_f32(const uint8_t* in, float* out, int n, int c, int h, int w, hipStream_t s) {
+    if (n < 1 || c < 1 || h < 1 || w < 1) { set_error("u8_to_f32: bad shape"); return -1; }
+    if ((size_t)h * w * c >= 0x7fffffffULL || n > 65535) { set_error("u8_to_f32: image too large (2^31 elements) or batch > 65535"); return -1; }
+    const int hw = h * w;
+    if (c == 3 && hw % 4 == 0 && aligned16(out) && ((uintptr_t)in & 3) == 0)
+        hipLaunchKernelGGL(u8_to_f32_rgb4_kernel, dim3((hw / 4 + 255) / 256, n), dim3(256), 0, s, in, out, hw);
+    else
+        hipLaunchKernelGGL(u8_to_f32_kernel, dim3((hw + 255) / 256, n), dim3(256), 0, s, in, out, c, hw);
+    return check_launch("u8_to_f32");
+}
+
 // ---- video post-pass (reference video/utils.py:89-105 warp_image, :223-229 blend_images) -------------------
 // out = u8( clip( (alpha * cur/255 + (1 - alpha) * warp(prev)/255) * 255, 0, 255 ) ), HWC uint8 frames;
 // warp(prev)(y, x) = bilinear sample of prev at (x + flow[0][y][x], y + flow[1][y][x]) with cv2.BORDER_REFLECT

@@ -24,6 +24,17 @@ class AdaINEngine:
     def synchronize(self):
         torch.cuda.synchronize(self.device)
 
+    def mark(self):
+        """A time stamp on the current stream (a HIP event); ``elapsed(a, b)`` gives the seconds between two of them once the
+        work in between has finished.  The job drivers time their phases with these instead of synchronising per phase."""
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(self.device))
+        return e
+
+    def elapsed(self, a, b):
+        b.synchronize()
+        return a.elapsed_time(b) * 1e-3
+
     def style_stats(self):
         """The current style's channel statistics (mean, std), each [1,512] on the GPU: what ``set_style`` computed."""
         return self.s_mean, self.s_std
@@ -43,15 +54,27 @@ class AdaINEngine:
         return self
 
     def features(self, images):
-        return rt.encode(images.to(self.device, torch.float32).contiguous(), self.enc)
+        return self._encode(images.to(self.device))
+
+    def _encode(self, content):
+        """float NCHW [n,3,h,w] in [0,1], or decoded frames uint8 NHWC [n,h,w,3] (ToTensor then runs inside the first layer's
+        kernel: same features bit for bit, a quarter of the bytes)."""
+        if content.dtype == torch.uint8:
+            return rt.encode_u8(content.contiguous(), self.enc)
+        return rt.encode(content.to(torch.float32).contiguous(), self.enc)
+
+    @staticmethod
+    def frame_size(content):
+        """(h, w) of a content batch in either form (float NCHW / uint8 NHWC)."""
+        return tuple(content.shape[1:3]) if content.dtype == torch.uint8 else tuple(content.shape[-2:])
 
     def stylize(self, content, alpha=0.5, pmap=None):
-        """content [n,3,h,w] on the GPU -> stylised [n,3,8*hc,8*wc].  ``pmap`` [1|n,1,hc,wc] switches to the
-        depth-aware blend (test.py:70); otherwise the alpha blend (test.py:80)."""
+        """content [n,3,h,w] float (or [n,h,w,3] uint8) on the GPU -> stylised [n,3,8*hc,8*wc].  ``pmap`` [1|n,1,hc,wc] switches
+        to the depth-aware blend (test.py:70); otherwise the alpha blend (test.py:80)."""
         assert 0.0 <= alpha <= 1.0
         if self.s_mean is None:
             raise rt.AdainHipError("set_style() first")
-        f = rt.encode(content, self.enc)
+        f = self._encode(content)
         c_mean, c_std = rt.mean_std(f, True)
         if pmap is not None:
             g = rt.blend_pmap(f, True, c_mean, c_std, self.s_mean, self.s_std, pmap)
@@ -62,25 +85,30 @@ class AdaINEngine:
     def stylize_depth(self, content, depth_maps, offset=0.15, prominence=20):
         """Depth-aware path for a batch: ``depth_maps`` is a list of [h0,w0] GPU tensors, one per frame."""
         assert 0.0 <= offset <= 1.0
-        n, _, h, w = content.shape
+        h, w = self.frame_size(content)
         hc, wc = rt.encoded_size(h, w)
         p = torch.cat([rt.strength_map(d, hc, wc, offset, prominence) for d in depth_maps])
         return self.stylize(content, pmap=p)
 
     def composite(self, content, stylized, masks):
         """masks [n|1, 1|3, hm, wm] float -> content*(1-m) + resize(stylized)*m (test.py:222-236)."""
-        content = content.to(self.device, torch.float32).contiguous()
+        content = content.to(self.device)
+        content = rt.u8_to_f32(content.contiguous()) if content.dtype == torch.uint8 else content.to(torch.float32).contiguous()
         size = tuple(content.shape[-2:])
         m = rt.resize_nearest(masks.to(self.device, torch.float32), size)
         s = rt.resize_bilinear(stylized, size)
         return rt.mask_composite(content, s, m)
 
-    def to_u8(self, images):
-        return rt.quantize_u8(images)
+    def to_u8(self, images, out=None):
+        return rt.quantize_u8(images, out)
 
     def resize_area_u8(self, frames_u8, dsize):
         """cv2.resize(frame, dsize, interpolation=cv2.INTER_AREA) per frame (video/utils.py:352-353); dsize = (width, height)."""
         return rt.resize_area_u8(frames_u8, dsize)
+
+    def warp_blend_u8(self, cur, prev, flow, alpha=0.7):
+        """One step of the video recurrence: blend(cur, warp(prev, flow), alpha) on uint8 HWC frames (video/utils.py:89-105, :223-229)."""
+        return rt.warp_blend_u8(cur, prev, flow, alpha)
 
     def temporal_blend(self, frames_u8, flows, alpha=0.7):
         return temporal_blend(frames_u8, flows, alpha)

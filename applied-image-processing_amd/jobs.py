@@ -9,15 +9,27 @@
 Both sit on ``stylize_frames_sharded``: the frame index is cut into contiguous blocks (``sharding.shard_range``), every
 rank (one process per GPU) runs the batched engine on its block against replicated weights and style statistics, and the
 finished uint8 frames meet on ``dst`` in ONE gather (RCCL over xGMI when the process group's CUDA backend is ``nccl``).
-There is no other collective on the data path.  What is sequential in the reference stays on ``dst`` after the gather: the
-frame-to-frame warp / blend recurrence and (by default) the file writes.
+There is no other collective on the data path, and nothing inside the frame loop synchronises the device or talks to another
+rank: one one-word status all_reduce per job (``sharding.agree_geometry``: every rank learns whether all blocks finished and
+what a finished frame looks like) precedes the gather, one device synchronisation ends the job.  What is sequential in the
+reference stays on ``dst`` after the gather: the frame-to-frame warp / blend recurrence and (by default) the file writes.
+
+Host side of a job (the reference goes file -> PIL -> tensor -> device per frame, test.py:190-204): ``FrameFeeder`` decodes /
+fetches the frames of the next sub-batches on a worker thread, stages them in pinned buffers and uploads them on a copy stream
+while the compute stream works on the current sub-batch.  Decoded frames travel as uint8 HWC (3 bytes per pixel; ToTensor runs
+on the device, bit-identical to the host's ``/ 255``); ``FileSink`` brings finished uint8 frames back with asynchronous copies
+and writes the image files on worker threads.
 
 The engine is passed in (``engine.AdaINEngine`` on a GPU); the drivers only use its methods, so the multi-process logic is
 exercised on CPU under ``gloo`` with a stand-in engine (tests/test_distributed_gloo.py).
 """
+import queue
+import threading
 import time
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -39,29 +51,346 @@ def style_schedule(n_frames, n_styles):
     return out
 
 
-def _dist_on(group):
-    return dist.is_available() and dist.is_initialized()
-
-
 def _rank_world(group):
-    if _dist_on(group):
-        return dist.get_rank(group), dist.get_world_size(group)
-    return 0, 1
+    return sh.rank_world(group)
 
 
-def host_barrier(group=None):
-    """Host-side rendezvous of the ranks (an all_reduce of one CPU word: it rides the CPU backend of a
-    "cpu:gloo,cuda:nccl" group and never touches the GPUs)."""
-    if _dist_on(group):
-        dist.all_reduce(torch.zeros(1), group=group)
+def host_barrier(group=None, device=None):
+    """Host-side rendezvous of the ranks (see ``sharding.host_barrier``)."""
+    sh.host_barrier(group, device)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# frames on their way to the device
+# ---------------------------------------------------------------------------------------------------------------------------------
+def as_frame(x):
+    """One frame in the form the drivers move it, and its kind: ``"u8"`` = a decoded frame uint8 [h,w,3] (an RGB PIL image,
+    a numpy array or a tensor: what the reference holds BEFORE ToTensor, test.py:190-200; ToTensor then runs on the device) or
+    ``"f32"`` = an already transformed float tensor [3,h,w] in [0,1] (a fourth channel is dropped)."""
+    if not isinstance(x, (torch.Tensor, np.ndarray)):          # a PIL image
+        if getattr(x, "mode", None) == "RGB":
+            x = np.asarray(x)
+        else:
+            from .AdaIN.test import _to_tensor
+
+            x = _to_tensor(x)
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if x.dtype == torch.uint8:
+        if x.dim() != 3 or x.shape[2] != 3:
+            raise ValueError(f"a uint8 frame must be [h,w,3], got {tuple(x.shape)}")
+        return x, "u8"
+    if x.dim() != 3 or x.shape[0] not in (3, 4):
+        raise ValueError(f"a float frame must be [3,h,w] (or [4,h,w]), got {tuple(x.shape)}")
+    return x[:3].to(torch.float32), "f32"
+
+
+class _Batch:
+    __slots__ = ("i", "j", "content", "depth", "mask", "ready", "slot")
+
+    def __init__(self, i, j, content, depth=None, mask=None, ready=None, slot=None):
+        self.i, self.j, self.content, self.depth, self.mask, self.ready, self.slot = i, j, content, depth, mask, ready, slot
+
+
+class FrameFeeder:
+    """Feeds ``frames[lo:hi]`` to the compute loop as sub-batches that are already on the device.
+
+    A worker thread fetches the frames (``frames[k]`` may decode a file), cuts sub-batches (at most ``sub_batch`` frames of
+    one style, one size and one kind), copies them into a pinned staging slot and uploads the slot on a dedicated copy stream;
+    the per-frame proximity maps and masks of the sub-batch ride along.  ``depth`` slots are in flight: the upload of sub-batch
+    k+1 (and the decode of k+2) overlaps the kernels of sub-batch k.  The consumer waits on the sub-batch's HIP event on ITS
+    stream (no host synchronisation) and calls ``release`` once its last kernel reading the slot is enqueued.
+
+    ``frames`` may offer ``block(i, j)`` -> a ready [j-i, ...] tensor of frames i..j-1 of one size (device-resident frame
+    stores hand out views: no staging, no copy).  On a CPU engine (tests) the same thread and cutting logic run without
+    pinned memory or streams."""
+
+    def __init__(self, frames, lo, hi, style_of, sub_batch, device, depth_maps=None, masks=None, depth=3, cuts=()):
+        self.frames, self.lo, self.hi, self.style_of, self.sub_batch = frames, lo, hi, style_of, max(1, int(sub_batch))
+        self.cuts = set(cuts)              # frame indices at which a sub-batch must end (chunk borders of a chunked gather)
+        self.device = torch.device(device)
+        self.depth_maps, self.masks = depth_maps, masks
+        self.cuda = self.device.type == "cuda"
+        self.nslots = max(2, int(depth))
+        self.q = queue.Queue()
+        self.free = threading.Semaphore(self.nslots)
+        self.stop = threading.Event()
+        self.h2d_bytes = 0
+        self.fetch_s = 0.0
+        if self.cuda:
+            self.copy_stream = torch.cuda.Stream(self.device)
+            self.compute_stream = torch.cuda.current_stream(self.device)
+            self.pinned, self.dev = {}, {}         # (slot, "content" | "mask" | "depth") -> staging buffers
+            self.h2d_done = [None] * self.nslots
+            self.consumed = [None] * self.nslots
+        self.thread = threading.Thread(target=self._run, name="adain-frame-feeder", daemon=True)
+        self.thread.start()
+
+    # ---- worker thread ----------------------------------------------------------------------------------------------------------
+    def _cut(self):
+        """Yields (i, j, frames-or-block, kind) for consecutive sub-batches of [lo, hi)."""
+        k, carry = self.lo, None
+        block = getattr(self.frames, "block", None)
+        while k < self.hi:
+            i = k
+            if block is not None:
+                j = i + 1
+                while j < self.hi and j - i < self.sub_batch and self.style_of[j] == self.style_of[i] and j not in self.cuts:
+                    j += 1
+                t = block(i, j)
+                yield i, j, t, ("u8" if t.dtype == torch.uint8 else "f32")
+                k = j
+                continue
+            items, kind = [], None
+            while k < self.hi and len(items) < self.sub_batch and self.style_of[k] == self.style_of[i] and not (items and k in self.cuts):
+                fr, kd = carry if carry is not None else as_frame(self.frames[k])
+                carry = None
+                if items and (kd != kind or fr.shape != items[0].shape or fr.device != items[0].device):
+                    carry = (fr, kd)          # another size / kind: it opens the next sub-batch
+                    break
+                items.append(fr)
+                kind = kd
+                k += 1
+            yield i, k, items, kind
+
+    def _upload(self, host):
+        """A one-off upload (shapes that do not fit the slot buffers): pinned copy + asynchronous H2D on the copy stream."""
+        t = host if host.is_pinned() else host.pin_memory()
+        d = t.to(self.device, non_blocking=True)
+        d.record_stream(self.compute_stream)             # allocated under the copy stream, read by the compute stream
+        self.h2d_bytes += host.numel() * host.element_size()
+        return d
+
+    def _stage(self, s, name, items):
+        """Host tensors ``items`` (one shape, one dtype) -> the slot's pinned buffer ``name`` (one memcpy each, no intermediate
+        stack) -> the slot's device buffer, asynchronously on the copy stream (the caller holds the stream context and has made
+        the stream wait for the slot's previous consumers).  Returns the device view [len(items), ...]."""
+        nb = len(items)
+        shape = (self.sub_batch,) + tuple(items[0].shape)
+        key = (s, name)
+        pin = self.pinned.get(key)
+        if pin is None or pin.shape != shape or pin.dtype != items[0].dtype:
+            pin = self.pinned[key] = torch.empty(shape, dtype=items[0].dtype, pin_memory=True)
+            self.dev[key] = torch.empty(shape, dtype=items[0].dtype, device=self.device)
+        for q_, it in enumerate(items):
+            pin[q_].copy_(it)
+        self.dev[key][:nb].copy_(pin[:nb], non_blocking=True)
+        self.h2d_bytes += nb * items[0].numel() * items[0].element_size()
+        return self.dev[key][:nb]
+
+    def _extras(self, i, j):
+        """The sub-batch's proximity maps (float32 [h0,w0] each) and masks ([1|3,hm,wm] each; bool / uint8 / float) as host or
+        device tensors, still one per frame."""
+        depth = mask = None
+        if self.depth_maps is not None:
+            depth = [torch.as_tensor(self.depth_maps[k], dtype=torch.float32) for k in range(i, j)]
+        if self.masks is not None:
+            ms = [torch.as_tensor(self.masks[k]) for k in range(i, j)]
+            mask = [m if m.dtype in (torch.uint8, torch.bool, torch.float32) else m.float() for m in ms]
+        return depth, mask
+
+    @staticmethod
+    def _uniform(ts):
+        return all(t.shape == ts[0].shape and t.dtype == ts[0].dtype and not t.is_cuda for t in ts)
+
+    def _run(self):
+        try:
+            if self.cuda:
+                torch.cuda.set_device(self.device)
+            b = 0
+            for i, j, items, kind in self._cut():
+                if self.stop.is_set():
+                    return
+                t0 = time.perf_counter()
+                depth, mask = self._extras(i, j)
+                self.fetch_s += time.perf_counter() - t0
+                self.free.acquire()
+                if self.stop.is_set():
+                    return
+                s = b % self.nslots
+                b += 1
+                ready = None
+                if not self.cuda:
+                    content = items if isinstance(items, torch.Tensor) else torch.stack(items)
+                    mask = torch.stack(mask) if mask is not None else None
+                else:
+                    if self.h2d_done[s] is not None:
+                        self.h2d_done[s].synchronize()                   # the slot's previous uploads have left its pinned buffers
+                    with torch.cuda.stream(self.copy_stream):
+                        if self.consumed[s] is not None:
+                            self.copy_stream.wait_event(self.consumed[s])      # the kernels that read this slot have finished
+                        staged = False
+                        if isinstance(items, torch.Tensor):              # a ready block (device-resident store)
+                            content = items
+                        elif items[0].is_cuda:
+                            content = None                               # stacked by the consumer on its own stream
+                        else:
+                            content = self._stage(s, "content", items)
+                            staged = True
+                        if depth is not None and not all(d.is_cuda for d in depth):
+                            if self._uniform(depth):
+                                dd = self._stage(s, "depth", depth)
+                                depth = [dd[k] for k in range(len(depth))]
+                            else:
+                                depth = [d if d.is_cuda else self._upload(d) for d in depth]
+                            staged = True
+                        if mask is not None:
+                            if all(m.is_cuda for m in mask):
+                                mask = torch.stack(mask)
+                                mask.record_stream(self.compute_stream)
+                            elif self._uniform(mask):
+                                mask = self._stage(s, "mask", mask)
+                            else:
+                                mask = self._upload(torch.stack([m.cpu() for m in mask]))
+                            staged = True
+                        if staged:
+                            ready = torch.cuda.Event()
+                            ready.record(self.copy_stream)
+                            self.h2d_done[s] = ready
+                    if content is None:
+                        content = items                                  # list of device tensors
+                self.q.put(_Batch(i, j, content, depth, mask, ready, s))
+            self.q.put(None)
+        except BaseException as e:                                       # re-raised by the consumer
+            self.q.put(e)
+
+    # ---- consumer ---------------------------------------------------------------------------------------------------------------
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            if item.ready is not None:
+                torch.cuda.current_stream(self.device).wait_event(item.ready)
+            if isinstance(item.content, list):                           # frames that already were device tensors
+                item.content = torch.stack(item.content)
+            yield item
+
+    def release(self, batch):
+        """The consumer has enqueued the last kernel that reads ``batch``'s slot."""
+        if self.cuda and batch.slot is not None:
+            e = torch.cuda.Event()
+            e.record(torch.cuda.current_stream(self.device))
+            self.consumed[batch.slot] = e
+        self.free.release()
+
+    def close(self):
+        self.stop.set()
+        for _ in range(self.nslots + 1):
+            self.free.release()
+        self.thread.join(30)
+
+
+class HostCopier:
+    """Asynchronous device -> pinned-host copies on a stream of their own: a finished block leaves the device while the next
+    sub-batch's kernels run.  ``finish()`` waits for all of them."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.bytes = 0
+        if self.cuda:
+            self.stream = torch.cuda.Stream(self.device)
+
+    def copy(self, dst_host, src):
+        """dst_host.copy_(src) once the work enqueued so far on the current stream has finished."""
+        self.bytes += src.numel() * src.element_size()
+        if not self.cuda:
+            dst_host.copy_(src)
+            return
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            dst_host.copy_(src, non_blocking=True)
+            src.record_stream(self.stream)
+
+    def finish(self):
+        if self.cuda:
+            self.stream.synchronize()
+
+
+class FileSink:
+    """Writes finished uint8 frames to image files off the compute path: the device -> host copy of a sub-batch runs on its own
+    stream into a pinned buffer, a worker thread waits for it and encodes / saves the files (PIL), so the next sub-batch's
+    kernels are already running.  ``close()`` waits for every file and re-raises the first error."""
+
+    def __init__(self, device, workers=4):
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="adain-file-sink")
+        self.futures = []
+        self.d2h_bytes = 0
+        if self.cuda:
+            self.stream = torch.cuda.Stream(self.device)
+
+    @staticmethod
+    def _save(arr, path):
+        from PIL import Image
+
+        Image.fromarray(arr[:, :, 0] if arr.shape[2] == 1 else arr).save(str(path))
+
+    def write(self, u8_block, paths):
+        """u8_block [k,h,w,c] on the engine's device (finished on the current stream); paths: k file paths."""
+        if not self.cuda:
+            host, done = u8_block, None
+        else:
+            cur = torch.cuda.current_stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            host = torch.empty(u8_block.shape, dtype=torch.uint8, pin_memory=True)
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ready)
+                host.copy_(u8_block, non_blocking=True)
+                u8_block.record_stream(self.stream)
+                done = torch.cuda.Event()
+                done.record(self.stream)
+            self.d2h_bytes += u8_block.numel()
+
+        def job():
+            if done is not None:
+                done.synchronize()
+            arr = host.numpy()
+            for k, p in enumerate(paths):
+                self._save(arr[k], p)
+
+        self.futures.append(self.pool.submit(job))
+
+    def close(self):
+        err = None
+        for f in self.futures:
+            try:
+                f.result()
+            except BaseException as e:      # keep waiting for the others, report the first
+                err = err or e
+        self.pool.shutdown(wait=True)
+        self.futures = []
+        if err is not None:
+            raise err
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _mark(engine):
+    m = getattr(engine, "mark", None)
+    return m() if m is not None else time.perf_counter()
+
+
+def _elapsed(engine, a, b):
+    f = getattr(engine, "elapsed", None)
+    return f(a, b) if f is not None else b - a
 
 
 def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, depth_maps=None, depth_offset=0.15,
                            depth_prominence=20, masks=None, post=None, sub_batch=4, group=None, dst=0, gather=True,
-                           require_transport=None, style_cache=None):
-    """Stylises ``frames`` (a sequence of [3,h,w] float tensors in [0,1], all one size, indexed lazily: a rank only ever
-    touches its own block) and returns ``(frames_u8, info)``: the uint8 frames [n,H,W,3] in frame order on rank ``dst``
-    (None on the other ranks, the local block when ``gather=False``) and a dict with the shard, timings and the transport.
+                           require_transport=None, style_cache=None, out_hw=None, gather_chunks=1, agree=True, sink=None,
+                           prefetch=3, host_out=None):
+    """Stylises ``frames`` (a sequence indexed lazily: a rank only ever touches its own block; an element is a decoded
+    frame uint8 [h,w,3] / RGB PIL image, or a float tensor [3,h,w] in [0,1]) and returns ``(frames_u8, info)``: the uint8
+    frames [n,H,W,3] in frame order on rank ``dst`` (None on the other ranks; with ``gather=False`` the local block — a
+    list of per-size blocks if the frames have several sizes, None if a ``sink`` took them) and a dict with the shard, the
+    timings and the transport.
 
     styles          one style tensor [1|.,3,hs,ws] or a list of them; ``style_of[i]`` picks the style of frame i
                     (``style_schedule``); every style image is encoded once per rank and call, its 2 x 512 statistics
@@ -71,8 +400,20 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
     masks           optional sequence of [1|3,hm,wm] masks -> content-mask composite (test.py:222-236).
     post            optional ``f(u8_block) -> u8_block`` applied per sub-batch on the owning rank BEFORE the gather
                     (frame-local work such as the INTER_AREA resize, so the gather moves the small frames).
+    sink            optional ``f(i, j, u8_block)`` called with every finished sub-batch (frames i..j-1) on the owning rank.
     require_transport   e.g. "rccl": raise before any work if the gather would use another transport.
-    """
+    out_hw          (H, W) of a finished frame, if the caller knows it: lets ``agree=False`` jobs and chunked gathers run with
+                    ranks whose block is empty.
+    gather_chunks   1: ONE gather when every rank has finished (after the status word: an error anywhere raises everywhere).
+                    k > 1: the block is gathered in k pieces, each issued asynchronously as soon as it is finished so that it
+                    overlaps the rest of the compute (status word at the end only).
+    host_out        a (pinned) uint8 host tensor [n,H,W,3]: finished frames are also copied into it, asynchronously on a copy
+                    stream as they become available — per sub-batch on a single rank (or with ``gather=False``: every rank fills
+                    the rows of its own block), per gathered piece on ``dst`` otherwise — and are all there when the call returns.
+    agree           False skips the per-job status word (per-step benchmark mode: every rank must have frames or ``out_hw``).
+
+    The gather needs one frame size over the whole job; with ``gather=False`` sizes may differ from frame to frame (a
+    sub-batch ends where the size changes).  Nothing in the frame loop synchronises the device or communicates."""
     rank, world = _rank_world(group)
     n = len(frames)
     lo, hi = sh.shard_range(n, world, rank)
@@ -82,71 +423,184 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
     if len(style_of) != n:
         raise ValueError("style_of needs one style index per frame")
     dev = engine.device
+    gathering = gather and world > 1
     transport = None
-    if gather and world > 1:
+    chunks = max(1, int(gather_chunks)) if gathering else 1
+    if gathering:
         transport = sh.device_transport(torch.empty(0, dtype=torch.uint8, device=dev), group)
         if require_transport and transport != require_transport:
             raise RuntimeError(f"final gather would run over {transport!r}, not {require_transport!r}")
+        if (chunks > 1 or not agree) and n < world and out_hw is None:        # the same decision on every rank
+            raise ValueError("a job with fewer frames than ranks needs out_hw for chunked or unagreed gathers")
+    counts = sh.shard_counts(n, world)
+    # chunk c of rank r = frames [lo_r + a, lo_r + b) with (a, b) = chunk_bounds(counts[r], chunks)[c]
+    my_chunks = sh.chunk_bounds(hi - lo, chunks)
 
-    t0 = time.perf_counter()
-    blocks = []
-    cur_style = None
-    stats = style_cache if style_cache is not None else {}
-    i = lo
-    while i < hi:
-        j = i + 1
-        while j < hi and j - i < sub_batch and style_of[j] == style_of[i]:
-            j += 1
-        if style_of[i] != cur_style:
-            cur_style = style_of[i]
-            if cur_style not in stats:
-                stats[cur_style] = engine.set_style(style_list[cur_style]).style_stats()
-            engine.use_style_stats(stats[cur_style])
-        content = torch.stack([frames[k][:3] for k in range(i, j)]).to(dev, torch.float32)
-        if depth_maps is not None:
-            out = engine.stylize_depth(content, [depth_maps[k].to(dev, torch.float32) for k in range(i, j)], depth_offset,
-                                       depth_prominence)
+    info = {"rank": rank, "world": world, "shard": (lo, hi), "transport": transport, "gathers": 0}
+    t_host0 = time.perf_counter()
+    m0 = _mark(engine)
+    blocks, shapes = [], set()             # finished sub-batches (i, j, u8) of this rank, their frame shapes
+    pending, landed = [], []               # chunked gather: (chunk, counts, finish closure) in flight; (first frame, block) arrived on dst
+    next_chunk = 0
+    err = None
+    copier = HostCopier(dev) if host_out is not None else None
+    feeder = FrameFeeder(frames, lo, hi, style_of, sub_batch, dev, depth_maps, masks, depth=prefetch,
+                         cuts=[lo + b for (_, b) in my_chunks] if chunks > 1 else ())
+
+    def chunk_ready(c, done_upto):
+        return lo + my_chunks[c][1] <= done_upto
+
+    def issue_chunk(c):
+        a, b = my_chunks[c]
+        part = [u8 for (i, j, u8) in blocks if lo + a <= i and j <= lo + b]
+        if part:
+            local_c = torch.cat(part) if len(part) > 1 else part[0]
         else:
-            out = engine.stylize(content, alpha)
-        if masks is not None:
-            m = torch.stack([torch.as_tensor(masks[k]).float() for k in range(i, j)]).to(dev)
-            out = engine.composite(content, out, m)
-        u8 = engine.to_u8(out)
-        blocks.append(post(u8) if post is not None else u8)
-        i = j
-    if blocks:
-        local = torch.cat(blocks) if len(blocks) > 1 else blocks[0]
-    else:                      # a rank without frames still takes part in the gather; it learns the frame shape from dst's peers
-        local = None
-    info = {"rank": rank, "world": world, "shard": (lo, hi), "transport": transport}
-    engine.synchronize()
-    info["compute_s"] = time.perf_counter() - t0
-    if not gather or world == 1:
-        if local is None:
-            local = torch.empty((0,), dtype=torch.uint8, device=dev)
-        info["gather_s"] = 0.0
+            geom = tuple(out_hw) + (3,) if out_hw is not None else tuple(blocks[0][2].shape[1:])
+            local_c = torch.empty((0,) + geom, dtype=torch.uint8, device=dev)
+        cnts = [sh.chunk_bounds(cr, chunks)[c][1] - sh.chunk_bounds(cr, chunks)[c][0] for cr in counts]
+        info["gathers"] += 1
+        land_pending()                     # the previous piece has long arrived: hand it on before queueing the next
+        pending.append((c, cnts, sh.gather_frames(local_c, n, dst=dst, group=group, async_op=True, counts=cnts)))
+
+    def land_pending():
+        """Waits (on the stream) for the gathered pieces issued so far and files them on dst: into the job's result and, piece
+        by piece, into ``host_out``."""
+        while pending:
+            c, cnts, fin = pending.pop(0)
+            got = fin()
+            if rank != dst:
+                continue
+            at = 0
+            for r in range(world):
+                r_lo = sh.shard_range(n, world, r)[0]
+                a = sh.chunk_bounds(counts[r], chunks)[c][0]
+                if cnts[r]:
+                    landed.append((r_lo + a, got[at:at + cnts[r]]))
+                    if copier is not None:
+                        copier.copy(host_out[r_lo + a:r_lo + a + cnts[r]], got[at:at + cnts[r]])
+                at += cnts[r]
+
+    try:
+        cur_style = None
+        stats = style_cache if style_cache is not None else {}
+        for batch in feeder:
+            i, j = batch.i, batch.j
+            if style_of[i] != cur_style:
+                cur_style = style_of[i]
+                if cur_style not in stats:
+                    stats[cur_style] = engine.set_style(style_list[cur_style]).style_stats()
+                engine.use_style_stats(stats[cur_style])
+            content = batch.content
+            if batch.depth is not None:
+                out = engine.stylize_depth(content, [d.to(dev, torch.float32) for d in batch.depth], depth_offset, depth_prominence)
+            else:
+                out = engine.stylize(content, alpha)
+            if batch.mask is not None:
+                out = engine.composite(content, out, batch.mask.to(dev).float())
+            u8 = engine.to_u8(out)
+            feeder.release(batch)
+            if post is not None:
+                u8 = post(u8)
+            shapes.add(tuple(u8.shape[1:]))
+            if sink is not None:
+                sink(i, j, u8)
+            if copier is not None and not gathering:
+                copier.copy(host_out[i:j], u8)
+            if gather or sink is None:
+                blocks.append((i, j, u8))
+            if chunks > 1:
+                if len(shapes) > 1:
+                    raise ValueError("stylize_frames_sharded: the gather needs one frame size over the whole job")
+                while next_chunk < chunks - 1 and chunk_ready(next_chunk, j):
+                    issue_chunk(next_chunk)
+                    next_chunk += 1
+    except Exception as e:                 # agreed on below: every rank raises, none is left waiting in the gather
+        err = e
+    finally:
+        feeder.close()
+    info["h2d_bytes"] = feeder.h2d_bytes
+    info["fetch_s"] = feeder.fetch_s
+    m1 = _mark(engine)
+    info["enqueue_s"] = time.perf_counter() - t_host0      # host time to fetch, upload and launch the whole block
+
+    def finish_times(m2=None):
+        if copier is not None:
+            copier.finish()
+            info["d2h_bytes"] = copier.bytes
+        engine.synchronize()
+        info["compute_s"] = _elapsed(engine, m0, m1)
+        info["gather_s"] = _elapsed(engine, m1, m2) if m2 is not None else 0.0
+
+    if not gathering:
+        if err is not None:
+            raise err
+        finish_times()
+        if sink is not None and not gather:
+            return None, info
+        if len(shapes) > 1:
+            if gather:
+                raise ValueError("stylize_frames_sharded: the gather needs one frame size over the whole job")
+            return [u8 for (_, _, u8) in blocks], info
+        if blocks:
+            local = torch.cat([u8 for (_, _, u8) in blocks]) if len(blocks) > 1 else blocks[0][2]
+        else:
+            geom = tuple(out_hw) + (3,) if out_hw is not None else (0, 0, 3)
+            local = torch.empty((0,) + geom, dtype=torch.uint8, device=dev)
         return local, info
-    # frame geometry is identical on every rank that has frames; ranks with none (n < world) get it from rank 0's block
-    shape = torch.tensor(list(local.shape[1:]) if local is not None else [0, 0, 0], dtype=torch.int64)
-    shapes = [torch.zeros_like(shape) for _ in range(world)]
-    dist.all_gather(shapes, shape, group=group)                  # host metadata (CPU backend), 24 bytes per rank
-    geom = next((tuple(int(v) for v in s_) for s_ in shapes if int(s_.sum()) > 0), None)
-    if geom is None:
-        return (torch.empty((0,), dtype=torch.uint8, device=dev) if rank == dst else None), info
-    for s_ in shapes:
-        if int(s_.sum()) > 0 and tuple(int(v) for v in s_) != geom:
+
+    # ---- the job's status word, then its gather ------------------------------------------------------------------------------------
+    geom = next(iter(shapes)) if len(shapes) == 1 else None
+    if agree:
+        ok, geom_all, uniform = sh.agree_geometry(err is None, shapes, group, dev)
+        if err is not None:
+            raise err
+        if not ok:
+            raise RuntimeError("stylize_frames_sharded: another rank failed; job abandoned before the gather")
+        if not uniform:
             raise ValueError("stylize_frames_sharded: the gather needs one frame size on every rank")
-    if local is None:
-        local = torch.empty((0,) + geom, dtype=torch.uint8, device=dev)
-    g0 = time.perf_counter()
-    out = sh.gather_frames(local, n, dst=dst, group=group)
-    engine.synchronize()
-    info["gather_s"] = time.perf_counter() - g0
+        if geom_all is not None and out_hw is not None and tuple(out_hw) != tuple(geom_all[:2]):
+            raise ValueError(f"stylize_frames_sharded: out_hw {tuple(out_hw)} but the finished frames are {tuple(geom_all[:2])}")
+        geom = geom_all
+    else:
+        if err is not None:
+            raise err
+        if len(shapes) > 1:
+            raise ValueError("stylize_frames_sharded: the gather needs one frame size over the whole job")
+        if geom is None and out_hw is not None:
+            geom = tuple(out_hw) + (3,)
+    if geom is None:                       # an empty job: nothing to gather anywhere
+        finish_times()
+        return (torch.empty((0, 0, 0, 3), dtype=torch.uint8, device=dev) if rank == dst else None), info
+    if chunks == 1:
+        if blocks:
+            local = torch.cat([u8 for (_, _, u8) in blocks]) if len(blocks) > 1 else blocks[0][2]
+        else:
+            local = torch.empty((0,) + tuple(geom), dtype=torch.uint8, device=dev)
+        info["gathers"] += 1
+        out = sh.gather_frames(local, n, dst=dst, group=group)
+        if copier is not None and rank == dst:
+            copier.copy(host_out, out)
+    else:
+        if out_hw is None and not blocks:
+            out_hw = tuple(geom[:2])
+        while next_chunk < chunks:
+            issue_chunk(next_chunk)
+            next_chunk += 1
+        land_pending()
+        out = None
+        if rank == dst:
+            out = torch.empty((n,) + tuple(geom), dtype=torch.uint8, device=dev)
+            for first, blk in landed:
+                out[first:first + blk.shape[0]].copy_(blk)
+    m2 = _mark(engine)
+    finish_times(m2)
     return out, info
 
 
 def video_style_transfer_sharded(engine, frames, styles, *, flows=None, target_resolution=None, blend_alpha=0.7, depth_maps=None,
-                                 offset=0.30, prominence=20, alpha=0.5, sub_batch=4, group=None, dst=0, require_transport=None):
+                                 offset=0.30, prominence=20, alpha=0.5, sub_batch=4, group=None, dst=0, require_transport=None,
+                                 gather_chunks=1):
     """The video caller (reference video/utils.py:297-369) over a frame list: per-frame AdaIN sharded over the ranks (styles
     switching through the clip as ``style_schedule`` says when several are given; depth-aware when ``depth_maps`` are
     given, which is how the reference runs it: ``use_depth=True``, offset 0.30, prominence 20), ``cv2.resize(...,
@@ -156,12 +610,14 @@ def video_style_transfer_sharded(engine, frames, styles, *, flows=None, target_r
     estimator is OpenCV's and stays outside).  Returns ``(frames_u8 on dst | None, info)``."""
     n = len(frames)
     style_list = list(styles) if isinstance(styles, (list, tuple)) else [styles]
-    post = None
+    post = out_hw = None
     if target_resolution is not None:
         post = lambda u8: engine.resize_area_u8(u8, target_resolution)
+        out_hw = (int(target_resolution[1]), int(target_resolution[0]))
     out, info = stylize_frames_sharded(engine, frames, style_list, style_of=style_schedule(n, len(style_list)), alpha=alpha,
                                        depth_maps=depth_maps, depth_offset=offset, depth_prominence=prominence, post=post,
-                                       sub_batch=sub_batch, group=group, dst=dst, require_transport=require_transport)
+                                       sub_batch=sub_batch, group=group, dst=dst, require_transport=require_transport,
+                                       out_hw=out_hw, gather_chunks=gather_chunks)
     if out is not None and flows is not None and n > 1:
         t0 = time.perf_counter()
         out = engine.temporal_blend(out, flows.to(out.device, torch.float32), blend_alpha)
@@ -172,23 +628,25 @@ def video_style_transfer_sharded(engine, frames, styles, *, flows=None, target_r
 
 def precompute_guides_sharded(engine, views, names, output_dir, style, *, masks=None, content_size=512, crop=False, alpha=0.5,
                               depth_maps=None, depth_offset=0.5, depth_prominence=20, save_ext=".jpg", sub_batch=4, group=None,
-                              dst=0, write="dst", require_transport=None):
+                              dst=0, write="dst", require_transport=None, writers=4):
     """The guide-image precompute of the reference's Style_3DGS/train.py:86-115 over all training views, sharded: every view
     is resized as ``adain_inference(content_size=...)`` resizes it (test.py:190-200), stylised, composited with its mask
     (``gt_image_np > 0``, train.py:97) and saved as ``<output_dir>/<name><save_ext>`` — the reference's naming, so the guide
     loss (train.py:208-221) reads the files back unchanged.  ``write="dst"``: the uint8 views are gathered and rank ``dst``
-    writes every file (views must then share one size); ``write="local"``: every rank writes its own block and nothing is
-    gathered.  Every rank returns the full {name: Path} map once all files exist."""
+    writes every file (views must then share one size); ``write="local"``: every rank writes its own block as it is
+    finished — nothing is gathered and the views may have any mix of sizes.  The views are decoded / resized on a worker
+    thread ahead of the kernels and travel to the device as uint8; the files are encoded and written by ``writers`` threads
+    behind them.  Every rank returns the full {name: Path} map once all files exist (an error on any rank raises on all)."""
     from PIL import Image
 
-    from .AdaIN.test import test_transform
+    from .AdaIN.test import test_transform_u8
 
     if write not in ("dst", "local"):
         raise ValueError("write must be 'dst' or 'local'")
     rank, world = _rank_world(group)
     out_dir = Path(output_dir)
     out_dir.mkdir(exist_ok=True, parents=True)
-    tf = test_transform(content_size, crop)
+    tf = test_transform_u8(content_size, crop)
 
     class _Views:                         # lazy: a rank only opens and resizes the views of its own block
         def __len__(self):
@@ -198,24 +656,65 @@ def precompute_guides_sharded(engine, views, names, output_dir, style, *, masks=
             v = views[k]
             if isinstance(v, (str, Path)):
                 v = Image.open(str(v))
-            return tf(v) if not isinstance(v, torch.Tensor) else v
+            return v if isinstance(v, (torch.Tensor, np.ndarray)) else tf(v)
 
-    frames = _Views()
+    names = list(names)
     paths = {nm: out_dir / f"{nm}{save_ext}" for nm in names}
-    u8, info = stylize_frames_sharded(engine, frames, style, alpha=alpha, depth_maps=depth_maps, depth_offset=depth_offset,
-                                      depth_prominence=depth_prominence, masks=masks, sub_batch=sub_batch, group=group, dst=dst,
-                                      gather=(write == "dst"), require_transport=require_transport)
-    lo, hi = info["shard"]
+    sink = FileSink(engine.device, workers=writers)
+    err = None
+    info = {}
+    try:
+        if write == "local":
+            _, info = stylize_frames_sharded(engine, _Views(), style, alpha=alpha, depth_maps=depth_maps, depth_offset=depth_offset,
+                                             depth_prominence=depth_prominence, masks=masks, sub_batch=sub_batch, group=group, dst=dst,
+                                             gather=False, sink=lambda i, j, u8: sink.write(u8, [paths[names[k]] for k in range(i, j)]))
+        else:
+            u8, info = stylize_frames_sharded(engine, _Views(), style, alpha=alpha, depth_maps=depth_maps, depth_offset=depth_offset,
+                                              depth_prominence=depth_prominence, masks=masks, sub_batch=sub_batch, group=group, dst=dst,
+                                              gather=True, require_transport=require_transport)
+            if rank == dst and len(names):
+                step = max(1, sub_batch)
+                for a in range(0, len(names), step):
+                    sink.write(u8[a:a + step], [paths[nm] for nm in names[a:a + step]])
+    except Exception as e:
+        err = e
     t0 = time.perf_counter()
-    if write == "dst":
-        if rank == dst:
-            arr = u8.cpu().numpy()
-            for k, nm in enumerate(names):
-                Image.fromarray(arr[k]).save(str(paths[nm]))
-    else:
-        arr = u8.cpu().numpy()
-        for k in range(lo, hi):
-            Image.fromarray(arr[k - lo]).save(str(paths[names[k]]))
+    try:
+        sink.close()
+    except Exception as e:
+        err = err or e
     info["write_s"] = time.perf_counter() - t0
-    host_barrier(group)                   # every file exists when any rank returns
+    info["d2h_bytes"] = sink.d2h_bytes
+    # every file exists when any rank returns - or every rank raises
+    all_ok = sh.agree(err is None, group, engine.device)
+    if err is not None:
+        raise err
+    if not all_ok:
+        raise RuntimeError("precompute_guides_sharded: another rank failed; the guide set is incomplete")
     return paths, info
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# timed job loop (bench.py --job; driven on CPU by tests/test_distributed_gloo.py)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def run_timed_jobs(job, steps, warmup, *, barrier, group=None):
+    """bench.py's contract around whole jobs: ``warmup`` untimed jobs, ``barrier()``, EXACTLY ``steps`` jobs, ``barrier()``;
+    returns (seconds as the MAX over the ranks, the last job's result, per-rank info of the last job).  ``job()`` runs one
+    whole sharded job (``stylize_frames_sharded`` ...) and returns ``(result, info)``; ``barrier()`` must leave this rank's
+    device idle and every other rank's too."""
+    res = info = None
+    for _ in range(warmup):
+        res, info = job()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res, info = job()
+    barrier()
+    dt = time.perf_counter() - t0
+    if sh.dist_on() and dist.get_world_size(group) > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        if "cpu" not in sh.backend_table(group):
+            t = t.to(info["device"]) if info and "device" in info else t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        dt = float(t.item())
+    return dt, res, info

@@ -31,6 +31,7 @@ SIGNATURES = {
     "adain_encoded_size": (None, [_c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "adain_encode_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "adain_encode": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_int, _c_int, _PP, _c_void_p]),
+    "adain_encode_u8": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_int, _c_int, _PP, _c_void_p]),
     "adain_encode_multi_workspace_bytes": (_c_size_t, [_c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "adain_encode_multi": (_c_int, [_c_int, _PP, _PP, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), _c_void_p,
                                     _c_void_p, _c_size_t, _PP, _c_void_p]),
@@ -48,6 +49,7 @@ SIGNATURES = {
     "adain_resize_nearest": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_mask_composite": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_quantize_u8": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "adain_u8_to_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_warp_blend_u8": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p]),
     "adain_resize_area_u8": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 6 + [_c_void_p]),
     "adain_nhwc_to_nchw": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
@@ -191,6 +193,23 @@ def encode(image, packed, events=None):
     with torch.cuda.device(image.device):
         _check(lib().adain_encode(image.data_ptr(), feat.data_ptr(), packed.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, ev,
                                   _stream()), "adain_encode")
+    return feat
+
+
+def encode_u8(frames_u8, packed, events=None):
+    """Decoded frames HWC uint8 [n,h,w,3] -> relu4_1 features NHWC [n,hc,wc,512]; ToTensor (v / 255) happens inside the first
+    layer's kernel: bit-identical to ``encode(u8_to_f32(frames_u8))``."""
+    x = _dev(frames_u8, "frames", torch.uint8)
+    if x.dim() != 4 or x.shape[3] != 3:
+        raise AdainHipError(f"encode_u8: expected uint8 [n,h,w,3], got {tuple(x.shape)}")
+    n, h, w, _ = x.shape
+    hc, wc = encoded_size(h, w)
+    feat = torch.empty((n, hc, wc, 512), dtype=torch.float32, device=x.device)
+    ws = workspace(x.device, "conv", lib().adain_encode_workspace_bytes(n, h, w))
+    ev, _keep = _event_array(events)
+    with torch.cuda.device(x.device):
+        _check(lib().adain_encode_u8(x.data_ptr(), feat.data_ptr(), packed.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, ev,
+                                     _stream()), "adain_encode_u8")
     return feat
 
 
@@ -340,13 +359,30 @@ def mask_composite(content, stylized, mask):
     return out
 
 
-def quantize_u8(img):
-    """NCHW float [n,c,h,w] -> NHWC uint8 [n,h,w,c] (x*255 + 0.5, clamp, truncate)."""
+def quantize_u8(img, out=None):
+    """NCHW float [n,c,h,w] -> NHWC uint8 [n,h,w,c] (x*255 + 0.5, clamp, truncate); ``out``: a contiguous uint8 [n,h,w,c] GPU
+    tensor to write into (a slice of a job's frame block)."""
     img = _dev(img, "image")
     n, c, h, w = img.shape
-    out = torch.empty((n, h, w, c), dtype=torch.uint8, device=img.device)
+    if out is None:
+        out = torch.empty((n, h, w, c), dtype=torch.uint8, device=img.device)
+    elif (not out.is_cuda or out.dtype != torch.uint8 or tuple(out.shape) != (n, h, w, c) or not out.is_contiguous()
+          or out.device != img.device):
+        raise AdainHipError(f"quantize_u8: out must be a contiguous uint8 {(n, h, w, c)} tensor on {img.device}")
     with torch.cuda.device(img.device):
         _check(lib().adain_quantize_u8(img.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "adain_quantize_u8")
+    return out
+
+
+def u8_to_f32(frames_u8):
+    """torchvision ToTensor on the device: NHWC uint8 [n,h,w,c] -> NCHW float [n,c,h,w] = v / 255 (bit for bit the host's)."""
+    x = _dev(frames_u8, "frames", torch.uint8)
+    if x.dim() != 4:
+        raise AdainHipError(f"u8_to_f32: expected uint8 [n,h,w,c], got {tuple(x.shape)}")
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().adain_u8_to_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "adain_u8_to_f32")
     return out
 
 

@@ -39,6 +39,56 @@ def uniform01(seed, n):
     return bits.astype(np.float32) * np.float32(2.0 ** -24)
 
 
+def uniform01_bits_torch(seed, n, device="cpu", start=0):
+    """The 24 random bits behind ``uniform01(seed, n)[start:start + n]`` as an int64 torch tensor on ``device`` — the same
+    counter-based splitmix64, in wrapping int64 arithmetic with logical shifts emulated by masks, so a GPU rebuilds a job's
+    synthetic frames bit for bit in microseconds (numpy on the host needs about a second per 1080p frame)."""
+    import torch
+
+    def lsr(x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    def mix(x):
+        x = x + _i64(0x9E3779B97F4A7C15)
+        z = x
+        z = (z ^ lsr(z, 30)) * _i64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * _i64(0x94D049BB133111EB)
+        return z ^ lsr(z, 31)
+
+    with np.errstate(over="ignore"):
+        base = int(_splitmix64(np.array([seed], dtype=np.uint64) * np.uint64(0xD1342543DE82EF95))[0])
+    ctr = torch.arange(start, start + n, dtype=torch.int64, device=device) + _i64(base)
+    return lsr(mix(ctr), 40)
+
+
+def _i64(u):
+    """A uint64 constant as the int64 with the same bits."""
+    u &= 0xFFFFFFFFFFFFFFFF
+    return u - (1 << 64) if u >= (1 << 63) else u
+
+
+def uniform01_torch(seed, n, device="cpu"):
+    """``uniform01`` on a torch device: bit-identical float32 values."""
+    import torch
+
+    return uniform01_bits_torch(seed, n, device).to(torch.float32) * (2.0 ** -24)
+
+
+def frame_u8_torch(seed, h, w, device="cpu", zero_fraction=0.0, zero_seed=0):
+    """A synthetic DECODED frame, uint8 [h,w,3] on ``device``: channel c of pixel (y, x) is the top 8 of the 24 random bits of
+    element (c, y, x) of ``image(seed, 1, h, w)`` (so ``frame / 255`` is that image quantised the way a decoded picture is).
+    ``zero_fraction`` > 0 blanks that share of the pixels (all channels exactly 0: the empty background of a 3DGS training
+    view, reference Style_3DGS/train.py:97 ``mask = gt_image_np > 0``), chosen by ``uniform01(zero_seed, h * w) < fraction``."""
+    import torch
+
+    bits = uniform01_bits_torch(seed, 3 * h * w, device)
+    fr = (bits >> 16).to(torch.uint8).view(3, h, w).permute(1, 2, 0).contiguous()
+    if zero_fraction > 0:
+        bg = uniform01_torch(zero_seed, h * w, device).view(h, w) < zero_fraction
+        fr[bg] = 0
+    return fr
+
+
 def uniform_sym(seed, shape, bound):
     """float32 array U(-bound, bound) of ``shape``."""
     n = int(np.prod(shape))

@@ -75,16 +75,31 @@ def _jpeg_roundtrip(u8):
 
 def _run(content_dir, style_paths, output_dir, flow_method, alpha, target_resolution, cancel_flag, offset, prominence, engine,
          vgg_str, decoder_str, depth_maps, intermediate_jpeg, group):
+    from . import sharding as sh
     from .engine import AdaINEngine
 
     os.makedirs(output_dir, exist_ok=True)
     names = _frame_files(content_dir)
-    if cancel_flag is not None and cancel_flag.is_set():
+    rank, world = sh.rank_world(group)
+    dev = engine.device if engine is not None else None
+    # Everything that can stop the job is settled BEFORE any rank starts computing, with one status word, so that no rank is
+    # ever left waiting in a collective for a peer that has returned or raised: cancellation (the flag is a per-process Event),
+    # and the optical-flow provider the rank-0 recurrence will need from the second frame on.
+    cancelled = cancel_flag is not None and cancel_flag.is_set()
+    need_flow = rank == 0 and len(names) > 1 and _flow_provider is None
+    go = sh.agree_min(0 if need_flow else 1 if cancelled else 2, group, dev)
+    if go == 0:
+        if need_flow:
+            estimate_optical_flow(None, None, None)            # raises the "no optical-flow provider" error
+        raise RuntimeError("video style transfer: rank 0 has no optical-flow provider (video.set_flow_provider)")
+    if go == 1:                                                # cancelled on some rank: every rank stops, as the reference loop does
         print("Stopping style transfer...")
         return None
+    if len(names) == 0:                                        # an empty directory: the reference's loop is a no-op
+        return Path(output_dir)
     if engine is None:
         engine = AdaINEngine(torch.load(vgg_str, map_location="cpu"), torch.load(decoder_str, map_location="cpu"))
-    tf = adain_test.test_transform(256, False)                 # adain_inference(content_size=256) of the reference loop
+    tf = adain_test.test_transform_u8(256, False)              # adain_inference(content_size=256) of the reference loop
     stf = adain_test.test_transform(512, False)                # its default style_size
 
     class Frames:                                             # lazily: a rank opens only the frames of its own block
@@ -104,7 +119,6 @@ def _run(content_dir, style_paths, output_dir, flow_method, alpha, target_resolu
             return torch.as_tensor(adain_test.midas_depth_map_est(Image.open(os.path.join(content_dir, names[k]))), dtype=torch.float32)
 
     styles = [stf(Image.open(p).convert("RGB")).unsqueeze(0) for p in style_paths]
-    rank = torch.distributed.get_rank(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
     # stylise (sharded), resize to the target resolution on the owning rank, gather; the recurrence needs the flows: rank 0 only
     post = None
     if intermediate_jpeg:
@@ -113,27 +127,39 @@ def _run(content_dir, style_paths, output_dir, flow_method, alpha, target_resolu
         engine, Frames(), styles, style_of=jobs.style_schedule(len(names), len(styles)), depth_maps=Depths(), depth_offset=offset,
         depth_prominence=prominence,
         post=(lambda u8: engine.resize_area_u8(post(u8) if post else u8, target_resolution)) if target_resolution is not None else post,
+        out_hw=(int(target_resolution[1]), int(target_resolution[0])) if target_resolution is not None else None,
         group=group)
-    if rank != 0 or frames_u8 is None:
-        jobs.host_barrier(group)
-        return None
-    n, h, w, _ = frames_u8.shape
-    prev = None
-    for i, name in enumerate(names):
-        if cancel_flag is not None and cancel_flag.is_set():
-            print("Stopping style transfer...")
-            break
-        cur = frames_u8[i]
-        if prev is not None:
-            flow = estimate_optical_flow(os.path.join(content_dir, names[i - 1]), os.path.join(content_dir, name), (w, h), flow_method)
-            from . import runtime as rt
-
-            cur = rt.warp_blend_u8(cur.contiguous(), prev, flow.to(cur.device), alpha)
-        Image.fromarray(cur.cpu().numpy()).save(os.path.join(output_dir, name))
-        print(f"Stylized and saved: {os.path.join(output_dir, name)}")
-        prev = cur
-    jobs.host_barrier(group)
-    return Path(output_dir)
+    err = None
+    if rank == 0:
+        # the frame-to-frame recurrence (video/utils.py:355-368) on the gathered frames; every frame is written by a worker
+        # thread behind an asynchronous device -> host copy while the next frame's warp / blend is already running
+        sink = jobs.FileSink(engine.device)
+        try:
+            n, h, w, _ = frames_u8.shape
+            prev = None
+            for i, name in enumerate(names):
+                if cancel_flag is not None and cancel_flag.is_set():
+                    print("Stopping style transfer...")
+                    break
+                cur = frames_u8[i]
+                if prev is not None:
+                    flow = estimate_optical_flow(os.path.join(content_dir, names[i - 1]), os.path.join(content_dir, name), (w, h), flow_method)
+                    cur = engine.warp_blend_u8(cur.contiguous(), prev, flow.to(cur.device), alpha)
+                sink.write(cur.unsqueeze(0), [os.path.join(output_dir, name)])
+                print(f"Stylized and saved: {os.path.join(output_dir, name)}")
+                prev = cur
+        except Exception as e:
+            err = e
+        try:
+            sink.close()
+        except Exception as e:
+            err = err or e
+    ok = sh.agree(err is None, group, engine.device)             # the other ranks leave with rank 0 - or raise with it
+    if err is not None:
+        raise err
+    if not ok:
+        raise RuntimeError("video style transfer: the post-pass failed on rank 0")
+    return Path(output_dir) if rank == 0 else None
 
 
 def apply_style_transfer_ada(content_dir, style_image_path, output_dir, flow_method="farneback", alpha=0.7, target_resolution=None,

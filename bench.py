@@ -19,6 +19,15 @@ device gather must run over RCCL ("nccl" backend): if the process group cannot p
 GPUs, the benchmark exits non-zero instead of silently degrading (``--rehearse`` allows both for single-GPU rehearsals and
 labels the JSON line).  The timed region is bracketed by barrier + synchronize; the MAX over ranks is reported.
 
+``--job`` (configs 4 / 5) runs the BASELINE job itself instead of one frame per GPU per step: 512 frames / 300 views
+(``--frames``) cut into contiguous blocks over the ranks (strong scaling: 64 per GPU at 8; 38 / 37 ragged), every rank's block
+resident in HBM as decoded uint8 frames, ``jobs.stylize_frames_sharded`` with ``--batch`` frames per sub-batch (no host
+collective and no device synchronisation inside the frame loop, one status word and ONE gather per job); a "step" is one whole
+job, ``value`` = job pixels / wall time barrier to barrier including the gather.  ``--host-frames`` keeps the frames in
+(pageable) host memory instead: the job driver's feeder stages them in pinned buffers and uploads them on a copy stream behind
+the kernels, and the gathered result is copied back to the host - the PCIe-inclusive rate of the same job, reported as
+``pcie_inclusive`` beside an HBM-resident ``value`` measured in the same run.
+
 Rank 0 prints ONE JSON line.
   roofline      the dominant kernel family (3x3 convolutions, fp32 MFMA): HIP events recorded by the C ABI on the launch stream
                 around every conv launch.  ``achieved`` = multiplies the kernel EXECUTES on the matrix pipe (the Winograd
@@ -39,6 +48,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -124,19 +134,76 @@ def synth_frame(config, index, h, w):
     return x
 
 
+def synth_weights():
+    return synth.to_torch(synth.vgg_state_dict(0, full=False)), synth.to_torch(synth.decoder_state_dict(0))
+
+
+JOB_FRAMES = {4: 512, 5: 300}        # BASELINE.json configs[3] / configs[4]
+
+
+class FrameStore:
+    """This rank's block [lo, hi) of a job's list of ``n`` decoded frames (uint8 [h,w,3]; SURVEY.md 8(d): video frames seed
+    7 + i, guide views seed 1000 + i with ~30 % exact-zero background), generated on the GPU (``synth.frame_u8_torch``: the
+    host generator's bits).  Resident in HBM it hands out views (``block``); with ``host=True`` the frames are pageable numpy
+    arrays, as a decoder would leave them.  Touching a frame of another rank's block is an error."""
+
+    def __init__(self, config, n, lo, hi, h, w, device, host=False):
+        self.n, self.lo, self.hi, self.host = n, lo, hi, host
+        base = {4: 7, 5: 1000}[config]
+        dev = torch.empty((hi - lo, h, w, 3), dtype=torch.uint8, device=device)
+        for k in range(lo, hi):
+            dev[k - lo] = synth.frame_u8_torch(base + k, h, w, device, zero_fraction=0.3 if config == 5 else 0.0, zero_seed=2000 + k)
+        torch.cuda.synchronize()
+        self.dev = None if host else dev
+        self.np = [dev[k].cpu().numpy() for k in range(hi - lo)] if host else None
+        if not host:
+            self.block = self._block             # only the HBM-resident store offers zero-copy blocks (jobs.FrameFeeder)
+
+    def __len__(self):
+        return self.n
+
+    def _own(self, k):
+        if not self.lo <= k < self.hi:
+            raise IndexError(f"frame {k} belongs to another rank")
+        return k - self.lo
+
+    def __getitem__(self, k):
+        return self.np[self._own(k)] if self.host else self.dev[self._own(k)]
+
+    def _block(self, i, j):
+        return self.dev[self._own(i):self._own(j - 1) + 1]
+
+
+class MaskStore:
+    """The masks of a guide-view job, ``view > 0`` as [3,h,w] (reference Style_3DGS/train.py:97), beside the frames: bool tensors
+    in HBM or numpy arrays on the host."""
+
+    def __init__(self, frames):
+        self.f = frames
+        if frames.host:
+            self.m = [np.ascontiguousarray((a > 0).transpose(2, 0, 1)) for a in frames.np]
+        else:
+            self.m = (frames.dev > 0).permute(0, 3, 1, 2).contiguous()
+
+    def __len__(self):
+        return self.f.n
+
+    def __getitem__(self, k):
+        return self.m[self.f._own(k)]
+
+
 class Step:
     """One pass of the hot path on device-resident inputs through the C ABI (see the module docstring)."""
 
-    def __init__(self, device, config=2, first_frame=0, size=None, style_size=512, batch=1, alpha=0.5):
+    def __init__(self, device, config=2, first_frame=0, size=None, style_size=512, batch=1, alpha=0.5, engine=None, weights=None):
         self.config, self.alpha, self.batch, self.device = config, alpha, batch, device
         self.h, self.w = SIZES[config]
         if size:
             self.h = self.w = size
         self.hs = self.ws = style_size
         self.first_frame = first_frame
-        self.vgg_sd = synth.to_torch(synth.vgg_state_dict(0, full=False))
-        self.dec_sd = synth.to_torch(synth.decoder_state_dict(0))
-        self.engine = engine_mod.AdaINEngine(self.vgg_sd, self.dec_sd, device)      # packs the weights once
+        self.vgg_sd, self.dec_sd = weights if weights is not None else synth_weights()
+        self.engine = engine if engine is not None else engine_mod.AdaINEngine(self.vgg_sd, self.dec_sd, device)      # packs the weights once
         self.enc, self.dec = self.engine.enc, self.engine.dec
         self.content = torch.cat([synth_frame(config, first_frame + i, self.h, self.w) for i in range(batch)]).to(device)
         self.style = torch.from_numpy(synth.image(4, 1, self.hs, self.ws)).to(device)
@@ -169,6 +236,11 @@ class Step:
                     raise IndexError(f"frame {k} belongs to another rank")
                 return self.t[i]
 
+            def block(self, i, j):                      # resident frames: the job driver takes views, no staging
+                if not (step.first_frame <= i < j <= step.first_frame + step.batch):
+                    raise IndexError(f"frames {i}..{j - 1} belong to another rank")
+                return self.t[i - step.first_frame:j - step.first_frame]
+
         return Block(self.content), (Block(self.mask) if self.config == 5 else None)
 
     def run_job(self, n_job, gather, require_transport=None):
@@ -176,7 +248,8 @@ class Step:
         composite,] uint8, one gather to rank 0)."""
         frames, masks = self.job_inputs(n_job)
         res, info = jobs.stylize_frames_sharded(self.engine, frames, self.style, alpha=self.alpha, masks=masks, sub_batch=self.batch,
-                                                gather=gather, require_transport=require_transport, style_cache=self.style_cache)
+                                                gather=gather, require_transport=require_transport, style_cache=self.style_cache,
+                                                out_hw=(self.h, self.w), agree=False)       # per-step mode: no status word per step
         return res, info
 
     def flops_per_step(self):
@@ -359,7 +432,7 @@ def measure_pixel_kernels(device, reps=10):
     return out
 
 
-def cpu_baseline(step, gpu_out):
+def cpu_baseline(step, gpu_out, job_frames=None):
     """The oracle on this node's host cores, same workload, bounded sample (about 10-30 s): configs 2 / 3 whole forwards of
     the step's first frame; configs 4 / 5 two frames of the job (per-frame cost is constant)."""
     from oracle import adain_oracle as O
@@ -372,9 +445,12 @@ def cpu_baseline(step, gpu_out):
     cfg, h, w = step.config, step.h, step.w
     vgg_sd, dec_sd = step.vgg_sd, step.dec_sd
     s = step.style.cpu()
-    frames = [step.content[i:i + 1].cpu() for i in range(min(step.batch, 2))]
-    if cfg in (4, 5) and len(frames) < 2:
-        frames.append(synth_frame(cfg, step.first_frame + 1, h, w))
+    if job_frames is not None:     # --job: the job's first decoded frames (uint8 HWC) through ToTensor, as the reference loads them
+        frames = [f.cpu().permute(2, 0, 1).float().div(255).unsqueeze(0) for f in job_frames]
+    else:
+        frames = [step.content[i:i + 1].cpu() for i in range(min(step.batch, 2))]
+        if cfg in (4, 5) and len(frames) < 2:
+            frames.append(synth_frame(cfg, step.first_frame + 1, h, w))
 
     def forward(i):
         c = frames[i]
@@ -420,15 +496,21 @@ def cpu_baseline(step, gpu_out):
     }, psnr, rel
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 3 whole jobs with --job)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 1 job with --job)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[] index + 1 (default 2 = configs[1])")
     ap.add_argument("--size", type=int, default=0, help="override content H = W")
     ap.add_argument("--style-size", type=int, default=512)
-    ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 1); with --job: frames per sub-batch (default 4)")
+    ap.add_argument("--job", action="store_true", help="configs 4 / 5: run the BASELINE job (512 frames / 300 views) strong-scaled over the ranks")
+    ap.add_argument("--frames", type=int, default=0, help="--job: frames of the whole job (default 512 / 300)")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="--job: also time the job with its frames in host memory (pinned staging + copy stream) and the result copied back")
+    ap.add_argument("--gather-chunks", type=int, default=1, help="--job: pieces the one gather is issued in (overlapping the remaining compute)")
+    ap.add_argument("--n1-value", type=float, default=0.0, help="--job: the 1-GPU value of the same job, to report efficiency_vs_n1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1080p pixel-kernel bandwidth table")
     ap.add_argument("--pcie", action="store_true", help="also report the rate with the frame crossing PCIe both ways (never `value`)")
@@ -436,46 +518,184 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="single-GPU rehearsal of the multi-rank path: ranks may share a GPU and the gather may run over gloo (labelled in the JSON)")
     args = ap.parse_args()
+    if args.job and args.config not in (4, 5):
+        ap.error("--job runs the video job (--config 4) or the guide-view job (--config 5)")
+    if args.steps is None:
+        args.steps = 3 if args.job else 20
+    if args.warmup is None:
+        args.warmup = 1 if args.job else 3
+    if args.batch is None:
+        args.batch = 4 if args.job else 1
+    return args
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the AdaIN path has no CPU fallback)")
-    ndev = torch.cuda.device_count()
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    if local_world > ndev and not args.rehearse:
-        raise SystemExit(f"bench.py: {local_world} ranks on this node but only {ndev} GPU(s) visible: one process per GPU is the "
-                         "contract (RCCL rejects two ranks on one device); use --rehearse for a single-GPU rehearsal")
-    shared_gpu = local_world > ndev
-    torch.cuda.set_device(local_rank % ndev)
-    device = torch.device("cuda", local_rank % ndev)
-    use_dist = world > 1 or "RANK" in os.environ      # torch.distributed.run sets RANK even for one process
-    transport = None
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        # gloo carries the host-side rendezvous (barriers, the MAX of the step time); RCCL ("nccl") carries device
-        # tensors, i.e. the gather of the finished frames over xGMI.  With ranks sharing a GPU (--rehearse) RCCL cannot
-        # start, so the rehearsal gathers host copies over gloo: chosen here, up front, identically on every rank.
-        dist.init_process_group("gloo" if shared_gpu else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
-        transport = "gloo" if shared_gpu else sh.device_transport(torch.empty(0, dtype=torch.uint8, device=device))
-        if transport != "rccl" and not args.rehearse:
-            raise SystemExit(f"bench.py: the device gather would run over {transport!r}, not RCCL: refusing to report a multi-GPU number")
+
+class Ctx:
+    """Process / device / process-group setup shared by the per-step and the job mode."""
+
+    def __init__(self, args):
+        self.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if args.gpus != world:
+            if world == 1 and args.gpus > 1:
+                raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+            args.gpus = world
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the AdaIN path has no CPU fallback)")
+        ndev = torch.cuda.device_count()
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        if local_world > ndev and not args.rehearse:
+            raise SystemExit(f"bench.py: {local_world} ranks on this node but only {ndev} GPU(s) visible: one process per GPU is the "
+                             "contract (RCCL rejects two ranks on one device); use --rehearse for a single-GPU rehearsal")
+        self.shared_gpu = local_world > ndev
+        torch.cuda.set_device(local_rank % ndev)
+        self.device = torch.device("cuda", local_rank % ndev)
+        self.use_dist = world > 1 or "RANK" in os.environ      # torch.distributed.run sets RANK even for one process
+        self.transport = None
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            # gloo carries the host-side rendezvous (barriers, the MAX of the step time); RCCL ("nccl") carries device
+            # tensors, i.e. the gather of the finished frames over xGMI.  With ranks sharing a GPU (--rehearse) RCCL cannot
+            # start, so the rehearsal gathers host copies over gloo: chosen here, up front, identically on every rank.
+            dist.init_process_group("gloo" if self.shared_gpu else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+            self.transport = "gloo" if self.shared_gpu else sh.device_transport(torch.empty(0, dtype=torch.uint8, device=self.device))
+            if self.transport != "rccl" and not args.rehearse:
+                raise SystemExit(f"bench.py: the device gather would run over {self.transport!r}, not RCCL: refusing to report a multi-GPU number")
+
+    def barrier(self):
+        torch.cuda.synchronize()                      # this rank's GPU work is done ...
+        if self.use_dist:
+            dist.all_reduce(torch.zeros(1))           # ... and so is everybody else's (host rendezvous, gloo)
+        torch.cuda.synchronize()
+
+    def warm_transport(self, n_job, batch):
+        """Connection setup of the device transport (RCCL builds its communicator on first use) stays out of every timed region."""
+        if self.use_dist:
+            probe = torch.zeros((batch, 8, 8, 3), dtype=torch.uint8, device=self.device)
+            sh.gather_frames(probe if self.transport == "rccl" else probe.cpu(), n_job, dst=0, counts=[batch] * self.world)
+            self.barrier()
+
+    def finish(self):
+        if self.use_dist:
+            dist.all_reduce(torch.zeros(1))
+            dist.destroy_process_group()
+
+
+def base_result(args, ctx, value, ms, workload, parallelism, scaling):
+    return {
+        "metric": "stylized Mpixels/sec, AdaIN forward (encode content + encode style + AdaIN + decode)",
+        "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload + ", fp32, seeded synthetic weights (reference architecture)", "parallelism": parallelism},
+    }
+
+
+def main_job(args, ctx):
+    """``--job``: the BASELINE job of config 4 / 5 over all ranks (see the module docstring)."""
+    world, rank, device = ctx.world, ctx.rank, ctx.device
+    cfg = args.config
+    h, w = SIZES[cfg]
+    hs = ws = args.style_size
+    n_total = args.frames or JOB_FRAMES[cfg]
+    lo, hi = sh.shard_range(n_total, world, rank)
+    weights = synth_weights()
+    engine = engine_mod.AdaINEngine(weights[0], weights[1], device)
+    style = torch.from_numpy(synth.image(4, 1, hs, ws)).to(device)
+    style_cache = {}
+    via_rccl = ctx.use_dist and ctx.transport == "rccl"
+    if ctx.use_dist and not via_rccl:
+        raise SystemExit("bench.py --job: the job driver gathers device tensors; a single-GPU rehearsal over gloo is not supported here")
+
+    def make_job(frames, masks, host_result=None):
+        def job():
+            res, info = jobs.stylize_frames_sharded(engine, frames, style, alpha=0.5, masks=masks, sub_batch=args.batch, gather=ctx.use_dist,
+                                                    require_transport="rccl" if via_rccl and world > 1 else None, style_cache=style_cache,
+                                                    out_hw=(h, w), gather_chunks=args.gather_chunks,
+                                                    host_out=host_result)      # the finished frames leave the device behind the kernels
+            return res, info
+        return job
+
+    frames = FrameStore(cfg, n_total, lo, hi, h, w, device, host=False)
+    masks = MaskStore(frames) if cfg == 5 else None
+    ctx.warm_transport(world, 1)
+    dt, res, info = jobs.run_timed_jobs(make_job(frames, masks), args.steps, args.warmup, barrier=ctx.barrier)
+    if rank == 0:
+        assert res is not None and res.shape == (n_total, h, w, 3), (None if res is None else res.shape)
+    first_u8 = res[:2].clone() if rank == 0 else None
+    per_rank = [None] * world
+    mine = {k: round(float(info[k]), 4) for k in ("compute_s", "gather_s", "enqueue_s", "fetch_s")}
+    mine["frames"] = hi - lo
+    if ctx.use_dist:
+        dist.all_gather_object(per_rank, mine)
+    else:
+        per_rank = [mine]
+
+    pcie = None
+    if args.host_frames:
+        del res
+        host_frames = FrameStore(cfg, n_total, lo, hi, h, w, device, host=True)
+        host_masks = MaskStore(host_frames) if cfg == 5 else None
+        host_out = torch.empty((n_total, h, w, 3), dtype=torch.uint8).pin_memory() if rank == 0 else None
+        pdt, pres, pinfo = jobs.run_timed_jobs(make_job(host_frames, host_masks, host_out), args.steps, args.warmup, barrier=ctx.barrier)
+        if rank == 0:
+            assert torch.equal(host_out[:2], first_u8.cpu()), "host-resident job differs from the HBM-resident one"
+        pcie = {"value": round(n_total * h * w / 1e6 / (pdt / args.steps), 3), "unit": "Mpixels/s", "ms_per_step": round(pdt / args.steps * 1e3, 3),
+                "what": "the same job with its frames (and masks) in pageable host memory: pinned staging + uint8 upload on a copy stream "
+                        "behind the kernels, ToTensor on the device, the gathered uint8 result copied back to pinned host memory",
+                "h2d_bytes_rank0": int(pinfo["h2d_bytes"]), "fetch_s_rank0": round(float(pinfo["fetch_s"]), 4),
+                "bit_identical_to_resident": True}
+
+    if rank == 0:
+        sec_per_job = dt / args.steps
+        value = n_total * h * w / 1e6 / sec_per_job
+        what = {4: f"configs[3]: video job, {n_total} frames {h}x{w}", 5: f"configs[4]: 3DGS guide-view job, {n_total} views {h}x{w} with masks"}[cfg]
+        shard = sh.shard_counts(n_total, world)
+        workload = (f"{what}, one {hs}x{ws} style (statistics cached per rank), sub-batches of {args.batch}, decoded uint8 frames resident in HBM, "
+                    f"{'mask composite + ' if cfg == 5 else ''}uint8 out; a step = the whole job")
+        parallelism = (f"frame sharding x{world}: contiguous blocks {shard if world > 1 else ''} per rank, replicated weights and style statistics, "
+                       f"one status word + ONE gather of the uint8 frames to rank 0 per job" if ctx.use_dist else "single GPU, no collective")
+        result = base_result(args, ctx, value, sec_per_job * 1e3, workload, parallelism, "strong")
+        step = Step(device, config=cfg, first_frame=0, style_size=args.style_size, batch=args.batch, engine=engine, weights=weights)
+        roof, layers, secondary = measure_roofline(step, 5)
+        result["roofline"] = roof
+        result["secondary"] = secondary
+        result["step_tflops"] = round((step.flops_per_step() / args.batch * n_total) / sec_per_job / 1e12, 2)
+        result["job"] = {"driver": "jobs.stylize_frames_sharded", "frames": n_total, "frames_per_rank": shard, "sub_batch": args.batch,
+                         "gathers_per_job": info["gathers"], "gather_chunks": args.gather_chunks, "transport": ctx.transport,
+                         "per_rank": per_rank, "ms_per_frame": round(sec_per_job * 1e3 / max(shard), 4)}
+        if args.n1_value > 0:
+            result["job"]["efficiency_vs_n1"] = round(value / (args.n1_value * world), 4)
+        if pcie is not None:
+            result["pcie_inclusive"] = pcie
+        if world == 1 and not args.no_secondary:
+            result["secondary"] += measure_pixel_kernels(device)
+        if world == 1 and not args.no_cpu:
+            step.run()
+            torch.cuda.synchronize()
+            cb, psnr, rel = cpu_baseline(step, first_u8, job_frames=[frames[k] for k in range(min(2, n_total))])
+            result["cpu_baseline"] = cb
+            result["psnr_db_vs_cpu"] = round(psnr, 2) if psnr != float("inf") else "inf"
+            result["rel_l2_vs_cpu"] = float(f"{rel:.3e}")
+        if args.layers and layers:
+            for i, L in enumerate(layers):
+                print(f"layer {i:2d}: {L['gflop']:8.2f} GF  {L['ms']:8.4f} ms  {L['tflops']:7.2f} TF/s", file=sys.stderr)
+        print(json.dumps(result), flush=True)
+    ctx.finish()
+
+
+def main():
+    args = parse_args()
+    ctx = Ctx(args)
+    if args.job:
+        return main_job(args, ctx)
+    world, rank, device, use_dist, transport, shared_gpu = ctx.world, ctx.rank, ctx.device, ctx.use_dist, ctx.transport, ctx.shared_gpu
+    barrier = ctx.barrier
 
     step = Step(device, config=args.config, first_frame=rank * args.batch, size=args.size, style_size=args.style_size, batch=args.batch)
     h, w, hs, ws = step.h, step.w, step.hs, step.ws
     n_job = world * args.batch                        # frames of one step's job over all ranks
-
-    def barrier():
-        torch.cuda.synchronize()                      # this rank's GPU work is done ...
-        if use_dist:
-            dist.all_reduce(torch.zeros(1))           # ... and so is everybody else's (host rendezvous, gloo)
-        torch.cuda.synchronize()
 
     pending = []
     gathered = [None]
@@ -483,7 +703,7 @@ def main():
     job_info = {}
 
     def one_step():
-        if job_mode:          # the job driver: shard -> stylise -> [composite] -> uint8 -> gather (synchronous per job)
+        if job_mode:          # the job driver on one sub-batch per rank and step: shard -> stylise -> [composite] -> uint8 -> gather
             via_rccl = use_dist and transport == "rccl"
             res, info = step.run_job(n_job, gather=via_rccl, require_transport="rccl" if via_rccl and world > 1 else None)
             job_info.update(info)
@@ -507,12 +727,7 @@ def main():
         while pending:
             gathered[0] = pending.pop(0)()
 
-    if use_dist:
-        # connection setup of the device transport (RCCL builds its communicator on first use) stays out of every timed region,
-        # whatever --warmup is
-        probe = torch.zeros((args.batch, 8, 8, 3), dtype=torch.uint8, device=device)
-        sh.gather_frames(probe if transport == "rccl" else probe.cpu(), n_job, dst=0)
-        barrier()
+    ctx.warm_transport(n_job, args.batch)
     for _ in range(args.warmup):
         out = one_step()
     drain()
@@ -546,19 +761,11 @@ def main():
         ms = dt / args.steps * 1e3
         value = n_job * h * w / 1e6 / (dt / args.steps)
         roof, layers, secondary = measure_roofline(step, 5)
-        result = {
-            "metric": "stylized Mpixels/sec, AdaIN forward (encode content + encode style + AdaIN + decode)",
-            "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.config].format(h=h, w=w, hs=hs, ws=ws, b=args.batch)
-                                   + ", fp32, seeded synthetic weights (reference architecture)",
-                       "parallelism": f"frame sharding x{world}: contiguous frame blocks per rank, replicated weights and style "
-                                      "statistics, one gather of the uint8 frames to rank 0 per step" if use_dist else
-                                      "single GPU, no collective"},
-            "roofline": roof,
-            "secondary": secondary,
-        }
+        result = base_result(args, ctx, value, ms, WORKLOADS[args.config].format(h=h, w=w, hs=hs, ws=ws, b=args.batch),
+                             f"frame sharding x{world}: contiguous frame blocks per rank, replicated weights and style "
+                             "statistics, one gather of the uint8 frames to rank 0 per step" if use_dist else "single GPU, no collective", "weak")
+        result["roofline"] = roof
+        result["secondary"] = secondary
         result["step_tflops"] = round(step.flops_per_step() / (dt / args.steps) / 1e12 * world, 2)
         if use_dist:
             result["gather"] = {"in_timed_step": True, "transport": transport, "isolated_ms": round(gather_ms, 3),
@@ -584,7 +791,7 @@ def main():
         if world == 1 and not args.no_secondary:
             result["secondary"] += measure_pixel_kernels(device)
         if job_mode:
-            result["job_driver"] = "jobs.stylize_frames_sharded"
+            result["job_driver"] = "jobs.stylize_frames_sharded (one sub-batch per step; --job runs the whole BASELINE job)"
         if world == 1 and not args.no_cpu:
             out = step.run()
             torch.cuda.synchronize()
@@ -596,9 +803,7 @@ def main():
             for i, L in enumerate(layers):
                 print(f"layer {i:2d}: {L['gflop']:8.2f} GF  {L['ms']:8.4f} ms  {L['tflops']:7.2f} TF/s", file=sys.stderr)
         print(json.dumps(result), flush=True)
-    if use_dist:
-        dist.all_reduce(torch.zeros(1))
-        dist.destroy_process_group()
+    ctx.finish()
 
 
 if __name__ == "__main__":

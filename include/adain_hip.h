@@ -60,6 +60,12 @@ size_t adain_encode_workspace_bytes(int n, int h, int w);
 int adain_encode(const float* image_nchw, float* feat_nhwc, const float* packed, void* workspace,
                  size_t workspace_bytes, int n, int h, int w, void* const* layer_events, adain_stream_t stream);
 
+/* adain_encode on a decoded frame as the reference holds it before ToTensor (test.py:16-24, :190-204): image HWC uint8
+ * [n][h][w][3].  The first layer's kernel applies ToTensor itself (float(v) / 255, correctly rounded), so the features are
+ * bit-identical to adain_encode(ToTensor(image)) while the frame crosses PCIe and HBM as 3 bytes per pixel instead of 12. */
+int adain_encode_u8(const uint8_t* image_nhwc_u8, float* feat_nhwc, const float* packed, void* workspace,
+                    size_t workspace_bytes, int n, int h, int w, void* const* layer_events, adain_stream_t stream);
+
 /* The same encoder over `count` (1..4) image batches of different sizes in ONE pass: the content batch and the style image
  * of a style_transfer call go through the same vgg (test.py:57,63 / :76-77).  Results are bit-identical to one adain_encode
  * per batch; every generic 3x3 layer is a single launch whose tile list covers all batches, so the small style-branch layers
@@ -116,6 +122,10 @@ int adain_mask_composite(const float* content, const float* stylized, const floa
 /* ---- torchvision save_image quantiser (test.py:243-244): NCHW float -> NHWC u8, x*255+0.5 clamped ------ */
 int adain_quantize_u8(const float* image_nchw, uint8_t* out_nhwc, int n, int c, int h, int w,
                       adain_stream_t stream);
+
+/* ---- torchvision ToTensor (test.py:22): NHWC u8 [n][h][w][c] -> NCHW float [n][c][h][w], float(v) / 255 correctly rounded
+ * (bit for bit `tensor.float() / 255`); what the mask composite needs of a frame that was uploaded as uint8 ------------------ */
+int adain_u8_to_f32(const uint8_t* in_nhwc, float* out_nchw, int n, int c, int h, int w, adain_stream_t stream);
 
 /* ---- video post-pass (reference video/utils.py:89-105 warp_image + :223-229 blend_images) -------------------
  * HWC uint8 frames [h][w][c]; flow [2][h][w] (x then y displacement, as estimate_optical_flow returns it,

@@ -135,3 +135,19 @@ def test_shard_ranges():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
     with pytest.raises(ValueError):
         sh.shard_range(4, 2, 2)
+
+
+def test_device_side_generator_has_the_host_generators_bits():
+    """synth.uniform01_torch / frame_u8_torch (bench.py --job builds its 512 frames with them on the GPU) against the numpy generator."""
+    for seed in (0, 7, 1000, 2 ** 31 + 5):
+        assert np.array_equal(synth.uniform01(seed, 4099), synth.uniform01_torch(seed, 4099).numpy())
+    f = synth.frame_u8_torch(11, 9, 14).numpy()
+    assert np.array_equal(f, np.floor(synth.image(11, 1, 9, 14)[0] * 256).astype(np.uint8).transpose(1, 2, 0))
+
+
+def test_sharding_helpers_without_a_process_group():
+    assert sh.chunk_bounds(10, 3) == [(0, 4), (4, 7), (7, 10)] and sh.chunk_bounds(2, 3) == [(0, 1), (1, 2), (2, 2)]
+    assert sh.agree(True) and not sh.agree(False) and sh.agree_min(1) == 1
+    assert sh.agree_geometry(True, {(4, 6, 3)}) == (True, (4, 6, 3), True)
+    assert sh.agree_geometry(True, {(4, 6, 3), (4, 8, 3)})[2] is False
+    assert sh.agree_geometry(False, set()) == (False, None, True)
