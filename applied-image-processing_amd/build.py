@@ -12,8 +12,12 @@ CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libadain_hip.so")
 DIAG_LIB = os.path.join(PKG, "libadain_hip_diag.so")     # -DADAIN_DIAG: env tuning switches, stamp / timing-only kernels (tools/ only)
-SOURCES = ["conv.hip", "conv_wino.hip", "conv_wino3.hip", "conv_wino4.hip", "stats.hip", "pixel.hip", "api.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]
+# The product library holds only what its schedules launch; the direct implicit-GEMM family and the F(2x2,3x3) Winograd families
+# (rounds 1-2, A/B baselines with their own tests) are compiled into the diagnostic library only.
+SOURCES = ["conv_edge.hip", "conv_wino4.hip", "stats.hip", "pixel.hip", "api.hip"]
+DIAG_SOURCES = ["conv_direct.hip", "conv_wino.hip", "conv_wino3.hip"]
+# -fvisibility=hidden: the shared library exports the C ABI of include/adain_hip.h (ADAIN_API) and nothing else
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # The MFMA kernels carry their fp32 vector-ALU work (input transform, epilogues) next to the matrix instructions, where
 # v_pk_add_f32 / v_pk_fma_f32 issue far slower than the plain forms (MI355X_MICROARCH.md, "price of one filler beside
 # MFMAs"): keep hipcc from packing f32 pairs in those files.  Measured on the Winograd kernel: +7 %.
@@ -42,11 +46,12 @@ def build(force=False, verbose=False, diag=False):
     os.makedirs(objdir, exist_ok=True)
     lib = DIAG_LIB if diag else LIB
     flags = FLAGS + (["-DADAIN_DIAG"] if diag else []) + os.environ.get("ADAIN_EXTRA_HIPCC_FLAGS", "").split()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_utils.h"), os.path.join(INC, "adain_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_utils.h"), os.path.join(INC, "adain_hip.h"),
+               os.path.join(INC, "adain_hip_diag.h")]
     hipcc = _hipcc()
     jobs = []
     objs = []
-    for src in SOURCES:
+    for src in SOURCES + (DIAG_SOURCES if diag else []):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
@@ -71,4 +76,8 @@ def build(force=False, verbose=False, diag=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))
+    if "--all" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True))
+        print(build(force="--force" in sys.argv, verbose=True, diag=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

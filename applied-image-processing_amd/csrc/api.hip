@@ -4,6 +4,9 @@
 #include <stdlib.h>
 
 #include "../../include/adain_hip.h"
+#ifdef ADAIN_DIAG
+#include "../../include/adain_hip_diag.h"
+#endif
 #include "common.h"
 
 namespace adain {
@@ -33,11 +36,12 @@ static const Layer DEC[8] = {{512, 256, SRC_DIRECT, 0}, {256, 256, SRC_UP2X, 0},
 static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
 constexpr size_t FIRST_W = 2 * 14 * 64, FIRST_B = 64, LAST_W = 8 * 64 * 4, LAST_B = 3;
 
-// Which form of the generic 3x3 layers the encoder / decoder schedules run.  The product library always runs the Winograd
-// F(4,3) x F(2,3) kernels (FORM_WINO4); the diagnostic build (-DADAIN_DIAG) can select the others for A/B runs:
-// ADAIN_WINOGRAD=0 -> direct implicit GEMM, ADAIN_WINO_MH=34 / 3 / 4 / 1 / 2 -> F(2x2,3x3) kernels (bit-different, equally
-// valid results; all forms stay reachable and tested through adain_conv3x3 / adain_conv3x3_wino).
+// Which form of the generic 3x3 layers the encoder / decoder schedules run.  The product library always runs - and only
+// contains - the Winograd F(4,3) x F(2,3) kernels (FORM_WINO4); the diagnostic build (-DADAIN_DIAG) also holds the direct
+// implicit GEMM and the F(2x2,3x3) kernels and can select them for A/B runs: ADAIN_WINOGRAD=0 -> direct,
+// ADAIN_WINO_MH=34 / 3 / 4 / 1 / 2 -> F(2x2,3x3) (bit-different, equally valid results).
 enum { FORM_DIRECT = 0, FORM_WINO2 = 1, FORM_WINO4 = 2 };
+#ifdef ADAIN_DIAG
 static int wino_mh() {
     // 5 (default): F(4,3) x F(2,3); F(2x2,3x3) forms: 34 = persistent form (4) where the K loop is short (cin <= 64) and
     // register-resident-A form (3) elsewhere; 1, 2: LDS V image forms
@@ -48,6 +52,9 @@ static int conv_form() {
     static const int form = tune_env("ADAIN_WINOGRAD", 1) == 0 ? FORM_DIRECT : (wino_mh() == 5 ? FORM_WINO4 : FORM_WINO2);
     return form;
 }
+#else
+static constexpr int conv_form() { return FORM_WINO4; }
+#endif
 static size_t form_floats(int cin, int cout) { return (size_t)cin * cout * (conv_form() == FORM_WINO4 ? 24 : conv_form() == FORM_WINO2 ? 16 : 9); }
 
 // packed layout: [first w][first b] then per generic layer [w in the form the schedules launch][b], every block 256-B
@@ -86,25 +93,25 @@ static Offsets dec_offsets() {
 }
 
 static int pack_layer(const float* w, float* dst, int cin, int cout, hipStream_t s) {
-    switch (conv_form()) {
-        case FORM_WINO4: return launch_pack_wino4(w, dst, cin, cout, s);
-        case FORM_WINO2: return launch_pack_wino(w, dst, cin, cout, s);
-        default: return launch_pack_conv3x3(w, dst, cin, cout, s);
-    }
+#ifdef ADAIN_DIAG
+    if (conv_form() == FORM_WINO2) return launch_pack_wino(w, dst, cin, cout, s);
+    if (conv_form() == FORM_DIRECT) return launch_pack_conv3x3(w, dst, cin, cout, s);
+#endif
+    return launch_pack_wino4(w, dst, cin, cout, s);
 }
 
 static int launch_layer(ConvArgs& a, const float* packed, const Offsets& f, int i, int src, hipStream_t s) {
     a.bias = packed + f.b[i];
     a.wpk = packed + f.w[i];
-    switch (conv_form()) {
-        case FORM_WINO4: return launch_conv3x3_wino4(a, src, s);
-        case FORM_WINO2: {
-            int mh = wino_mh();
-            if (mh == 34) mh = a.cin <= 64 ? 4 : 3;      // persistent form where the K loop is short (tools/tune_conv.py)
-            return launch_conv3x3_wino(a, src, mh, s);
-        }
-        default: return launch_conv3x3(a, src, -1, s);
+#ifdef ADAIN_DIAG
+    if (conv_form() == FORM_WINO2) {
+        int mh = wino_mh();
+        if (mh == 34) mh = a.cin <= 64 ? 4 : 3;      // persistent form where the K loop is short (tools/tune_conv.py)
+        return launch_conv3x3_wino(a, src, mh, s);
     }
+    if (conv_form() == FORM_DIRECT) return launch_conv3x3(a, src, -1, s);
+#endif
+    return launch_conv3x3_wino4(a, src, s);
 }
 
 static int copy_bias(const float* src, float* dst, int n, hipStream_t s) {
@@ -384,18 +391,44 @@ int adain_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, adain_
     return launch_nchw_to_nhwc(in, out, n, c, hw, (hipStream_t)stream);
 }
 
+static unsigned long long* g_conv_dbg = nullptr;     // stamp buffer of the diagnostic kernels; always null in the product library
+
+size_t adain_conv3x3_wino4_packed_floats(int cin, int cout) { return (size_t)cin * cout * 24; }
+
+int adain_conv3x3_wino4_pack(const float* w, float* packed, int cin, int cout, adain_stream_t stream) {
+    if (!w || !packed) { set_error("conv3x3_wino4_pack: null pointer"); return ADAIN_EINVAL; }
+    return launch_pack_wino4(w, packed, cin, cout, (hipStream_t)stream);
+}
+
+int adain_conv3x3_wino(const float* in, float* out, const float* packed_w, const float* bias, int n, int h, int w, int hs, int ws,
+                       int cin, int cout, int src_mode, int relu, int pool_out, int mh, adain_stream_t stream) {
+    if (!in || !out || !packed_w || !bias) { set_error("conv3x3_wino: null pointer"); return ADAIN_EINVAL; }
+    ConvArgs a{};
+    a.in = in; a.out = out; a.wpk = packed_w; a.bias = bias;
+    a.n = n; a.H = h; a.W = w; a.Hs = hs; a.Ws = ws; a.cin = cin; a.cout = cout; a.relu = relu; a.pool_out = pool_out ? 1 : 0;
+    if (mh == 5) {      // F(4,3) x F(2,3): weights packed by adain_conv3x3_wino4_pack
+        a.dbg = g_conv_dbg;     // diagnostic builds only (tools/wino4_probe.py sets it)
+        return launch_conv3x3_wino4(a, src_mode, (hipStream_t)stream);
+    }
+#ifdef ADAIN_DIAG
+    a.dbg = (mh >= 13 && mh <= 17) ? g_conv_dbg : nullptr;
+    return launch_conv3x3_wino(a, src_mode, mh, (hipStream_t)stream);
+#else
+    set_error("conv3x3_wino: form %d exists in the diagnostic library only (this library runs form 5, F(4,3) x F(2,3))", mh);
+    return ADAIN_EINVAL;
+#endif
+}
+
+#ifdef ADAIN_DIAG
+/* ---- diagnostic library only (include/adain_hip_diag.h) -------------------------------------------------------------------- */
+int adain_debug_set_conv_stamp_buffer(void* p) { g_conv_dbg = (unsigned long long*)p; return 0; }
+
 size_t adain_conv3x3_packed_floats(int cin, int cout) { return (size_t)cin * cout * 9; }
 
 int adain_conv3x3_pack(const float* w, float* packed, int cin, int cout, adain_stream_t stream) {
     if (!w || !packed) { set_error("conv3x3_pack: null pointer"); return ADAIN_EINVAL; }
     return launch_pack_conv3x3(w, packed, cin, cout, (hipStream_t)stream);
 }
-
-static unsigned long long* g_conv_dbg = nullptr;     // stamp buffer of the diagnostic kernels; always null in the product library
-#ifdef ADAIN_DIAG
-/* diagnostic library only (libadain_hip_diag.so, tools/): a device buffer for the stamp / timing-only kernel variants */
-int adain_debug_set_conv_stamp_buffer(void* p) { g_conv_dbg = (unsigned long long*)p; return 0; }
-#endif
 
 int adain_conv3x3(const float* in, float* out, const float* packed_w, const float* bias, int n, int h, int w, int hs, int ws,
                   int cin, int cout, int src_mode, int relu, int pool_out, int variant, adain_stream_t stream) {
@@ -413,29 +446,6 @@ int adain_conv3x3_wino_pack(const float* w, float* packed, int cin, int cout, ad
     if (!w || !packed) { set_error("conv3x3_wino_pack: null pointer"); return ADAIN_EINVAL; }
     return launch_pack_wino(w, packed, cin, cout, (hipStream_t)stream);
 }
-
-size_t adain_conv3x3_wino4_packed_floats(int cin, int cout) { return (size_t)cin * cout * 24; }
-
-int adain_conv3x3_wino4_pack(const float* w, float* packed, int cin, int cout, adain_stream_t stream) {
-    if (!w || !packed) { set_error("conv3x3_wino4_pack: null pointer"); return ADAIN_EINVAL; }
-    return launch_pack_wino4(w, packed, cin, cout, (hipStream_t)stream);
-}
-
-int adain_conv3x3_wino(const float* in, float* out, const float* packed_w, const float* bias, int n, int h, int w, int hs, int ws,
-                       int cin, int cout, int src_mode, int relu, int pool_out, int mh, adain_stream_t stream) {
-    if (!in || !out || !packed_w || !bias) { set_error("conv3x3_wino: null pointer"); return ADAIN_EINVAL; }
-    if (mh == 5) {      // F(4,3) x F(2,3): weights packed by adain_conv3x3_wino4_pack
-        ConvArgs a5{};
-        a5.in = in; a5.out = out; a5.wpk = packed_w; a5.bias = bias;
-        a5.dbg = g_conv_dbg;     // diagnostic builds only (tools/wino4_probe.py sets it)
-        a5.n = n; a5.H = h; a5.W = w; a5.Hs = hs; a5.Ws = ws; a5.cin = cin; a5.cout = cout; a5.relu = relu; a5.pool_out = pool_out ? 1 : 0;
-        return launch_conv3x3_wino4(a5, src_mode, (hipStream_t)stream);
-    }
-    ConvArgs a{};
-    a.dbg = (mh >= 13 && mh <= 17) ? g_conv_dbg : nullptr;
-    a.in = in; a.out = out; a.wpk = packed_w; a.bias = bias;
-    a.n = n; a.H = h; a.W = w; a.Hs = hs; a.Ws = ws; a.cin = cin; a.cout = cout; a.relu = relu; a.pool_out = pool_out ? 1 : 0;
-    return launch_conv3x3_wino(a, src_mode, mh, (hipStream_t)stream);
-}
+#endif
 
 }  // extern "C"

@@ -1,4 +1,6 @@
-// gfx950 (CDNA4) convolution kernels for the AdaIN encoder/decoder.
+// gfx950 (CDNA4) direct implicit-GEMM 3x3 convolution kernels for the AdaIN encoder/decoder.
+// DIAGNOSTIC LIBRARY ONLY (libadain_hip_diag.so, build.py --diag): the product schedules run the F(4,3) x F(2,3) kernels of
+// conv_wino4.hip; this family (round 1's 0.9-of-peak direct form) stays built and tested there as the A/B baseline.
 //
 // Replaces the 29 torch.nn.Conv2d calls of the reference hot path (Style_3DGS/AdaIN/net.py:6-36
 // decoder, :38-69 encoder up to relu4_1) together with the ReflectionPad2d(1) in front of every
@@ -54,47 +56,6 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
         const int co = T * 32 + j, ci = c * KC + g * 8 + h * 4 + s;
         p[i] = w[((size_t)co * cin + ci) * 9 + tap];
     }
-}
-
-// conv0 (1x1, 3->3, net.py:39) folded into conv1_1 (3->64, net.py:41): a pointwise conv commutes
-// with reflection padding, so W'[o][c][t] = sum_c' W1[o][c'][t] W0[c'][c] and
-// b'[o] = b1[o] + sum_{c',t} W1[o][c'][t] b0[c'].  K index e = 3 tap + c for e < 27, and e = 27 multiplies a constant 1: its
-// weight is the bias b'[o], so the kernel's epilogue adds nothing (K = 28 = 14 MFMAs of K 2).
-// packed (A operand = weights): [2 cout tiles][14 steps][64 lanes] with cout = 32 T + lane % 32, e = 2 step + lane / 32.
-__global__ void pack_conv_first_kernel(const float* __restrict__ w0, const float* __restrict__ b0,
-                                       const float* __restrict__ w1, const float* __restrict__ b1,
-                                       float* __restrict__ p, float* __restrict__ bias_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    auto folded_bias = [&](int o) {
-        float b = b1[o];
-        for (int cp = 0; cp < 3; ++cp)
-            for (int t = 0; t < 9; ++t) b += w1[(o * 3 + cp) * 9 + t] * b0[cp];
-        return b;
-    };
-    if (i < 2 * 14 * 64) {
-        const int lane = i & 63, step = (i >> 6) % 14, T = i / (14 * 64);
-        const int o = T * 32 + (lane & 31), e = 2 * step + (lane >> 5);
-        float v;
-        if (e < 27) {
-            const int tap = e / 3, c = e % 3;
-            v = 0.f;
-            for (int cp = 0; cp < 3; ++cp) v += w1[(o * 3 + cp) * 9 + tap] * w0[cp * 3 + c];
-        } else {
-            v = folded_bias(o);
-        }
-        p[i] = v;
-    }
-    if (i < 64) bias_out[i] = folded_bias(i);
-}
-
-// last decoder conv (64->3, net.py:35): OIHW [3][64][3][3] -> the A operand of conv_last_kernel's 32 MFMAs,
-// [j = 8 loads][lane][s = 4]: row n' = lane % 32 = tap * 3 + cout (rows 27..31 zero), input channel (2j + lane / 32) * 4 + s
-__global__ void pack_conv_last_kernel(const float* __restrict__ w, float* __restrict__ p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 8 * 64 * 4) return;
-    const int s = i & 3, l = (i >> 2) & 63, j = i >> 8;
-    const int np = l & 31, ci = (2 * j + (l >> 5)) * 4 + s;
-    p[i] = np < 27 ? w[((np % 3) * 64 + ci) * 9 + np / 3] : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -620,265 +581,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_persist_kernel(ConvAr
 }
 
 // ---------------------------------------------------------------------------------------------
-// First layer: conv0 (1x1) folded into conv1_1 (3 -> 64), NCHW image in, NHWC out, ReLU.  HBM-bound: 12 B read and 256 B
-// written per pixel, so the kernel is built around its stores.
-//   * the reflect-padded 10 x 34 halo of an 8 x 32 pixel tile is staged once as three colour planes (at most 6 coalesced
-//     scalar loads per thread instead of 27 gathered ones);
-//   * MFMA with A = weights, B = pixels, K = 28: element e = 3 tap + colour is one dword LDS read (consecutive lanes read
-//     consecutive floats of a plane: no bank conflicts), e = 27 is a constant 1 against the folded bias; 14 MFMAs per
-//     32 x 32 output tile (round 2 started with K = 10 taps x [r, g, b, 0] = 40: 20 MFMAs); the weights (28 values per lane)
-//     stay in registers over the tile walk; a lane ends up holding 4 consecutive channels of one pixel;
-//   * each wave passes its two output rows through a private LDS row buffer so that every store instruction writes 1 KiB of
-//     contiguous NHWC memory (4 pixels x 64 channels, b128 per lane): 16 store instructions per wave and tile, where the
-//     accumulator layout itself would need 64 dword stores.
-// ---------------------------------------------------------------------------------------------
-constexpr int CF_OSTR = 68;      // floats per pixel of the row buffer: b128 writes of 8 consecutive pixels cover all 32 banks
-// Persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ...; the NEXT tile's halo pixels (at most 2 per thread) are loaded
-// into registers before the current tile's MFMAs and stores, so a workgroup's memory latency overlaps its own matrix work
-// (one tile per workgroup ran load -> MFMAs -> store strictly in sequence: 3.2 TB/s).
-// U8: the image arrives as uint8 HWC [n][H][W][3] (a decoded frame as PIL / the job drivers hold it) and the kernel applies
-// torchvision's ToTensor itself, float(v) / 255 with a correctly rounded fp32 division (reference test.py:22, :203): the result is
-// bit-identical to encoding the float NCHW tensor, the frame crosses PCIe and HBM as 3 instead of 12 bytes per pixel.
-template <bool U8>
-__global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restrict__ img_any,
-                                                            float* __restrict__ out, const float* __restrict__ wpk,
-                                                            const float* __restrict__ bias, int H, int W, int tiles_x,
-                                                            int tiles_y, int ntiles) {
-    const float* __restrict__ img_nchw = (const float*)img_any;
-    const uint8_t* __restrict__ img_u8 = (const uint8_t*)img_any;
-    constexpr int HALO = 10 * 34;
-    // the halo image (3 planes of 340 floats) and the four waves' row buffers (4 x 8.5 KiB) share the allocation: 34 KiB
-    __shared__ __attribute__((aligned(16))) float smem[4 * 32 * CF_OSTR];
-    static_assert(HALO * 3 <= 4 * 32 * CF_OSTR, "LDS layout");
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
-    const int tiles = tiles_x * tiles_y;
-    const size_t plane = (size_t)H * W;
-    const bool second = tid + 256 < HALO;          // threads 0..83 own a second halo pixel
-
-    // halo pixels p = tid and tid + 256 of tile t -> registers
-    f32x4 h0, h1;
-    auto halo_load = [&](int t) {
-        const int pt = t % tiles, img = t / tiles;
-        const int tx0 = (pt % tiles_x) * 32, ty0 = (pt / tiles_x) * 8;
-        auto pixel = [&](int p) {
-            const int hy = p / 34, hx = p - hy * 34;
-            const size_t at = (size_t)reflect1(ty0 + hy - 1, H) * W + reflect1(tx0 + hx - 1, W);
-            if constexpr (U8) {      // raw bytes stay in the registers (as integer bit patterns) until the LDS store: the loads stay in flight
-                const uint8_t* __restrict__ q = img_u8 + ((size_t)img * plane + at) * 3;
-                return f32x4{__uint_as_float((unsigned)q[0]), __uint_as_float((unsigned)q[1]), __uint_as_float((unsigned)q[2]), 0.f};
-            } else {
-                const float* __restrict__ q = img_nchw + (size_t)img * 3 * plane + at;
-                return f32x4{q[0], q[plane], q[2 * plane], 0.f};
-            }
-        };
-        h0 = pixel(tid);
-        if (second) h1 = pixel(tid + 256);
-    };
-
-    int t = blockIdx.x;
-    if (t >= ntiles) return;
-    halo_load(t);
-    // this lane's 2 x 14 weights (A operand; K index e = 2 g + lh) and the LDS offset of halo element e = (tap, channel): held
-    // in registers over the tile walk
-    float wf[2][14];
-    int koff[14];
-#pragma unroll
-    for (int g = 0; g < 14; ++g) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) wf[c][g] = wpk[(c * 14 + g) * 64 + lane];
-        const int e = min(2 * g + lh, 26), tap = e / 3;
-        koff[g] = (e % 3) * HALO + (tap / 3) * 34 + tap % 3;
-    }
-    for (;;) {
-        const int pt = t % tiles, img = t / tiles;
-        const int tx0 = (pt % tiles_x) * 32, ty0 = (pt / tiles_x) * 8;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {                    // planar [r | g | b][10][34]: the K reads below walk consecutive floats
-            if constexpr (U8) {                          // ToTensor: float(v) / 255, correctly rounded
-                smem[c * HALO + tid] = __fdiv_rn((float)__float_as_uint(h0[c]), 255.0f);
-                if (second) smem[c * HALO + tid + 256] = __fdiv_rn((float)__float_as_uint(h1[c]), 255.0f);
-            } else {
-                smem[c * HALO + tid] = h0[c];
-                if (second) smem[c * HALO + tid + 256] = h1[c];
-            }
-        }
-        __syncthreads();
-        const int tn = t + gridDim.x;
-        if (tn < ntiles) halo_load(tn);                  // in flight during this tile's MFMAs and stores
-
-        f32x16 acc[2][2];      // [channel tile][row of this wave]
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[c][m][r] = 0.f;
-#pragma unroll
-        for (int g = 0; g < 14; ++g) {
-            float xf[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                xf[m] = smem[(wave * 2 + m) * 34 + li + koff[g]];
-                if (g == 13) xf[m] = lh ? 1.0f : xf[m];                       // e = 27: the bias row
-            }
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) acc[c][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[c][g], xf[m], acc[c][m], 0, 0, 0);
-        }
-        __syncthreads();                                 // every wave has read its halo pixels: the row buffers may overwrite them
-
-        float* const st = smem + wave * (32 * CF_OSTR);
-        // the output descriptor starts at the tile's first row: offsets stay inside 8 rows, the image may be of any size
-        const size_t oleft = (size_t)(H - ty0) * W * 256;
-        const rsrc_t dst = make_rsrc(out + ((size_t)img * H + ty0) * W * 64, oleft < 0x7ffffff0ull ? (unsigned)oleft : 0x7ffffff0u);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int ry = wave * 2 + m, y = ty0 + ry;
-            // lane (li, lh) holds channels 32 c + 8 q + 4 lh + (0..3) of pixel li in acc[c][m][4 q .. 4 q + 3]
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int ch = 32 * c + 8 * q + 4 * lh;
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[c][m][4 * q + e], 0.f);      // the bias came in through K
-                    *(f32x4*)(st + li * CF_OSTR + ch) = v;
-                }
-            // the row buffer is private to the wave and LDS operations of one wave complete in order: no barrier
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int idx = k * 64 + lane, px = idx >> 4, q16 = idx & 15;
-                const f32x4 v = *(const f32x4*)(st + px * CF_OSTR + q16 * 4);
-                const int x = tx0 + px;
-                const int off = ((ry * W + x) * 64 + q16 * 4) * 4;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, (y < H && x < W) ? off : 0x7fffffff, 0, 0);
-            }
-        }
-        if (tn >= ntiles) break;
-        t = tn;
-        __syncthreads();                                 // the row buffers have been read: the next halo may overwrite them
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Last layer: 64 -> 3, no ReLU, NHWC in, NCHW image out (net.py:33-35).  N = 3 would waste 90 % of an MFMA tile as a
-// convolution, so the layer runs as a GEMM over INPUT pixels followed by a shifted sum:
-//     T[p][tap * 3 + co] = sum_ci x[p][ci] * w[co][ci][tap]          (K = 64, 27 of 32 MFMA rows used)
-//     out[y][x][co]      = bias[co] + sum_tap T[(y + dy, x + dx)][tap * 3 + co]
-// Every input pixel of the reflect-padded 18 x 34 halo of a 16 x 32 tile goes global memory -> registers -> B operand once
-// (no input staging in LDS, no 9-fold operand re-read); the weights are the A operand, 32 registers loaded once; T meets in
-// LDS (27 planes of 640 pixel slots) and each thread sums 9 x 3 values for its two pixels.  Per tile 20 x 32 MFMAs (4 waves x 5
-// groups of 32 halo pixels) = 5.4 GFLOP executed at 1024 x 1024 against 268 MB read: HBM-bound.
-// ---------------------------------------------------------------------------------------------
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
-}
-
-// CLD (diagnostic library only, ADAIN_CL_DIAG): 1 = no MFMAs (memory side alone: 60-63 us at 1024 x 1024), 2 = every load of a
-// group from one address (matrix side alone: 57 us), 4 = tiles in launch order (no XCD ranges: 68 us); product: 63-65 us.
-// TH = tile height: 16 (612 halo pixels = 20 groups of 32, 5 per wave; T = 69 KB: two workgroups per CU; the product) or 12
-// (476 pixels = 15 groups, the fourth wave takes 3; T = 52 KB: three workgroups per CU; diagnostic library, ADAIN_CL_TH=12:
-// 64.3-64.5 us against 64.5-65.5 on the same box - the third workgroup buys nothing here, unlike in conv_first).
-template <int CLD, int TH>
-__global__ __launch_bounds__(256, TH == 12 ? 3 : 2) void conv_last_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                          const float* __restrict__ wpk, const float* __restrict__ bias,
-                                                                          int H, int W, int tiles_x, int tiles_y) {
-    constexpr int NPX = (TH + 2) * HW_, NGRP = (NPX + 31) / 32, GPW = (NGRP + 3) / 4, SLOTS = NGRP * 32;
-    __shared__ float T[27 * SLOTS];                                          // [n'][pixel slot]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int px = lane & 31, lh = lane >> 5;
-    const int tiles = tiles_x * tiles_y;
-    // the workgroups of one XCD (blockIdx % 8) take a contiguous range of the tile list: the halo rows and columns that
-    // neighbouring tiles share are re-read from that XCD's L2 (speed only)
-    int lid = blockIdx.x;
-    if (CLD != 4 && (gridDim.x & 7) == 0) lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
-    const int pt = lid % tiles, img = lid / tiles;
-    const int tx0 = (pt % tiles_x) * TW, ty0 = (pt / tiles_x) * TH;
-    // the source descriptor starts at the first row the tile's halo can touch: offsets stay inside TH + 2 rows
-    const int srow0 = max(ty0 - 1, 0);
-    const size_t sleft = (size_t)(H - srow0) * W * 256;
-    const rsrc_t src = make_rsrc(in + ((size_t)img * H + srow0) * W * 64, sleft < 0x7ffffff0ull ? (unsigned)sleft : 0x7ffffff0u);
-    const rsrc_t wsr = make_rsrc(wpk, 8 * 64 * 16);
-
-    constexpr int PF = 2, RB = PF + 1;                            // pixel groups in flight ahead of the one being multiplied (3: 66.5 us, 2: 64.4-65.5)
-    f32x4 bx[RB][8];
-    // this wave's g-th group = group 4 g + wave of the tile: this lane's halo pixel, 8 x 16 bytes of its 256 (lane half lh takes
-    // the odd quads)
-    auto load_group = [&](auto G) {
-        constexpr int g = decltype(G)::value;
-        const int f = min((4 * g + wave) * 32 + px, NPX - 1);
-        const int hy = (f * 241) >> 13, hx = f - hy * HW_;                   // f / 34 for f < 1024
-        const int y = reflect1(ty0 + hy - 1, H), x = reflect1(tx0 + hx - 1, W);
-        const int off = ((y - srow0) * W + x) * 256 + lh * 16;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bx[g % RB][j] = buf_load4(src, off, CLD == 2 ? 0 : j * 32);
-    };
-    f32x4 wq[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wq[j] = buf_load4(wsr, lane * 16, j * 1024);
-    __builtin_amdgcn_sched_barrier(0);       // weights and two pixel groups in flight before the first MFMA (hipcc sinks the loads otherwise)
-    static_for<PF>([&](auto G) { if constexpr (decltype(G)::value < GPW) load_group(G); });
-    __builtin_amdgcn_sched_barrier(0);
-
-    static_for<GPW>([&](auto G) {
-        constexpr int g = decltype(G)::value;
-        if constexpr (g + PF < GPW) load_group(std::integral_constant<int, g + PF>{});   // (a group past the tile's last repeats its last pixel)
-        __builtin_amdgcn_sched_barrier(0);
-        if (4 * g + 3 < NGRP || 4 * g + wave < NGRP) {                        // wave-uniform, and only the last round can be short
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    if constexpr (CLD == 1) acc[(j * 4 + s) & 15] += wq[j][s] * bx[g % RB][j][s];
-                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j][s], bx[g % RB][j][s], acc, 0, 0, 0);
-                }
-            // D[row n' = (r & 3) + 8 (r >> 2) + 4 lh][column = this lane's pixel] -> plane n' of T: a store instruction writes 32
-            // consecutive floats per lane half, and the shifted sum below reads consecutive floats too (no bank conflicts either way)
-            float* rec = T + (lh * 4) * SLOTS + (4 * g + wave) * 32 + px;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int np = (r & 3) + 8 * (r >> 2);                        // + 4 lh
-                if (np + 4 < 27 || (np < 27 && lh == 0)) rec[np * SLOTS] = acc[r];
-            }
-        }
-    });
-    __syncthreads();
-
-    const int ox = tid & 31, oy = tid >> 5;
-    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int yy = oy + 8 * r;
-        if (yy >= TH) break;
-        float o0 = b0, o1 = b1, o2 = b2;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const float* tp = T + (dy * 3 + dx) * 3 * SLOTS + (yy + dy) * HW_ + ox + dx;
-                o0 += tp[0]; o1 += tp[SLOTS]; o2 += tp[2 * SLOTS];
-            }
-        const int y = ty0 + yy, x = tx0 + ox;
-        if (y < H && x < W) {
-            float* __restrict__ o = out + (size_t)img * 3 * H * W + (size_t)y * W + x;
-            o[0] = o0;
-            o[(size_t)H * W] = o1;
-            o[(size_t)2 * H * W] = o2;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------------------------
 int launch_pack_conv3x3(const float* w, float* p, int cin, int cout, hipStream_t s) {
@@ -887,17 +589,6 @@ int launch_pack_conv3x3(const float* w, float* p, int cin, int cout, hipStream_t
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(256), 0, s, w, p, cin, cout);
     return check_launch("pack_conv3x3");
-}
-
-int launch_pack_conv_first(const float* w0, const float* b0, const float* w1, const float* b1, float* p,
-                           float* bias_out, hipStream_t s) {
-    hipLaunchKernelGGL(pack_conv_first_kernel, dim3(7), dim3(256), 0, s, w0, b0, w1, b1, p, bias_out);
-    return check_launch("pack_conv_first");
-}
-
-int launch_pack_conv_last(const float* w, float* p, hipStream_t s) {
-    hipLaunchKernelGGL(pack_conv_last_kernel, dim3(8), dim3(256), 0, s, w, p);
-    return check_launch("pack_conv_last");
 }
 
 template <int MODE, int WM, int WN, int MT, int NT, int LDSPAD, int PF = 2, int EXPER = 0>
@@ -1012,50 +703,6 @@ int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s) 
     }
     set_error("conv3x3: unknown src_mode %d", src_mode);
     return -1;
-}
-
-int launch_conv_first(const void* img, int u8, float* out, const float* packed, const float* bias, int n, int H, int W,
-                      hipStream_t s) {
-    if (H < 2 || W < 2 || n < 1) { set_error("conv_first: H, W must be >= 2, got %dx%d", H, W); return -1; }
-    if ((size_t)W * 256 * 8 >= 0x7ffffff0ULL) { set_error("conv_first: eight 64-channel rows of width %d reach 2 GiB", W); return -1; }
-    const int tx = (W + 31) / 32, ty = (H + 7) / 8;
-    const long long ntiles = (long long)tx * ty * n;
-    if (ntiles > 0x7fffffffLL) { set_error("conv_first: bad grid"); return -1; }
-    const int cus = device_cu_count();
-    if (cus <= 0) { set_error("conv_first: device query failed"); return -1; }
-    long long per_cu = 3;                                                  // 3 workgroups per CU walk the tiles (same box: 2: 85 us, 3: 80, 4: 90)
-#ifdef ADAIN_DIAG
-    static const int wgs_env = tune_env("ADAIN_CF_WGS", 3);
-    per_cu = wgs_env;
-#endif
-    const long long grid = ntiles < per_cu * cus ? ntiles : per_cu * cus;
-    if (u8) hipLaunchKernelGGL(conv_first_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, img, out, packed, bias, H, W, tx, ty, (int)ntiles);
-    else hipLaunchKernelGGL(conv_first_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, img, out, packed, bias, H, W, tx, ty, (int)ntiles);
-    return check_launch("conv_first");
-}
-
-int launch_conv_last(const float* in, float* out, const float* packed, const float* bias, int n, int H, int W,
-                     hipStream_t s) {
-    if (H < 2 || W < 2 || n < 1) { set_error("conv_last: H, W must be >= 2, got %dx%d", H, W); return -1; }
-    if ((size_t)W * 256 * 18 >= 0x7ffffff0ULL) { set_error("conv_last: eighteen 64-channel rows of width %d reach 2 GiB", W); return -1; }
-    int th = 16;
-#ifdef ADAIN_DIAG
-    static const int th_env = tune_env("ADAIN_CL_TH", 16);
-    th = th_env == 12 ? 12 : 16;
-#endif
-    const int tx = (W + TW - 1) / TW, ty = (H + th - 1) / th;
-    if ((long long)tx * ty * n > 0x7fffffffLL) { set_error("conv_last: bad grid"); return -1; }
-    const dim3 grid((unsigned)(tx * ty * n));
-#ifdef ADAIN_DIAG
-    static const int cld = tune_env("ADAIN_CL_DIAG", 0);
-    if (cld == 1) hipLaunchKernelGGL((conv_last_kernel<1, 16>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
-    else if (cld == 2) hipLaunchKernelGGL((conv_last_kernel<2, 16>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
-    else if (cld == 4) hipLaunchKernelGGL((conv_last_kernel<4, 16>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
-    else if (th == 12) hipLaunchKernelGGL((conv_last_kernel<0, 12>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
-    else
-#endif
-    hipLaunchKernelGGL((conv_last_kernel<0, 16>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
-    return check_launch("conv_last");
 }
 
 }  // namespace adain

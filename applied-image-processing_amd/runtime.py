@@ -12,8 +12,10 @@ import threading
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# ADAIN_HIP_LIB selects another build of the same ABI (tools/ point it at libadain_hip_diag.so, build.py --diag)
-LIB_PATH = os.environ.get("ADAIN_HIP_LIB") or os.path.join(_PKG, "libadain_hip.so")
+# The product library.  Nothing in the environment can swap it: the diagnostic build (libadain_hip_diag.so, build.py --diag) is
+# loaded only by an explicit ``use_library(DIAG_LIB_PATH)`` call (tools/_diag.py, the tests of the older kernel families).
+LIB_PATH = os.path.join(_PKG, "libadain_hip.so")
+DIAG_LIB_PATH = os.path.join(_PKG, "libadain_hip_diag.so")
 
 SRC_DIRECT, SRC_UP2X, SRC_POOL2 = 0, 1, 2
 
@@ -54,14 +56,19 @@ SIGNATURES = {
     "adain_resize_area_u8": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 6 + [_c_void_p]),
     "adain_nhwc_to_nchw": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_nchw_to_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
+    "adain_conv3x3_wino4_packed_floats": (_c_size_t, [_c_int, _c_int]),
+    "adain_conv3x3_wino4_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
+    "adain_conv3x3_wino": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 11 + [_c_void_p]),
+}
+
+# entry points of include/adain_hip_diag.h: exported by the diagnostic library only
+DIAG_SIGNATURES = {
     "adain_conv3x3_packed_floats": (_c_size_t, [_c_int, _c_int]),
     "adain_conv3x3_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
     "adain_conv3x3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 11 + [_c_void_p]),
     "adain_conv3x3_wino_packed_floats": (_c_size_t, [_c_int, _c_int]),
     "adain_conv3x3_wino_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
-    "adain_conv3x3_wino4_packed_floats": (_c_size_t, [_c_int, _c_int]),
-    "adain_conv3x3_wino4_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
-    "adain_conv3x3_wino": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 11 + [_c_void_p]),
+    "adain_debug_set_conv_stamp_buffer": (_c_int, [_c_void_p]),
 }
 
 _lib = None
@@ -84,13 +91,29 @@ def lib():
                         "(there is no CPU / PyTorch fallback for the AdaIN path)"
                     )
                 l = ctypes.CDLL(LIB_PATH)
-                for name, (res, args) in SIGNATURES.items():
+                sigs = dict(SIGNATURES)
+                if hasattr(l, "adain_debug_set_conv_stamp_buffer"):      # the diagnostic build: both headers
+                    sigs.update(DIAG_SIGNATURES)
+                for name, (res, args) in sigs.items():
                     f = getattr(l, name)
                     f.restype, f.argtypes = res, args
                 if l.adain_abi_version() != 1:
                     raise AdainHipError("libadain_hip.so ABI version mismatch")
                 _lib = l
     return _lib
+
+
+def use_library(path):
+    """Switches the process to another build of the library (the diagnostic build, ``DIAG_LIB_PATH``; ``LIB_PATH`` switches
+    back).  Only tools/ and the tests of the older kernel families call this: the product path always runs ``LIB_PATH``."""
+    global _lib, LIB_PATH
+    with _lock:
+        _lib, LIB_PATH = None, path
+    return lib()
+
+
+def is_diag():
+    return hasattr(lib(), "adain_debug_set_conv_stamp_buffer")
 
 
 def _check(rc, what):
@@ -435,8 +458,15 @@ def nchw_to_nhwc(x):
     return out
 
 
-# --- single conv layer (tests / profiling) -------------------------------------------------------------
+# --- single conv layer (tests / profiling; everything but the F(4,3) x F(2,3) form needs the diagnostic library) ---------
+def _need_diag(what):
+    if not is_diag():
+        raise AdainHipError(f"{what} exists in the diagnostic library only: runtime.use_library(runtime.DIAG_LIB_PATH) "
+                            "(build it with `python applied-image-processing_amd/build.py --diag`)")
+
+
 def conv3x3_pack(w_oihw):
+    _need_diag("adain_conv3x3_pack")
     w = _dev(w_oihw, "weight")
     cout, cin = w.shape[:2]
     packed = torch.empty(lib().adain_conv3x3_packed_floats(cin, cout), dtype=torch.float32, device=w.device)
@@ -446,6 +476,7 @@ def conv3x3_pack(w_oihw):
 
 
 def conv3x3(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, pool_out=False, variant=-1):
+    _need_diag("adain_conv3x3")
     x = _dev(x_nhwc, "x")
     n, hs, ws_, cin = x.shape
     if src_mode == SRC_UP2X:
@@ -464,6 +495,8 @@ def conv3x3(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, pool_o
 
 def conv3x3_wino_pack(w_oihw, form=3):
     """Packed transformed weights for conv3x3_wino; form 5 (F(4,3) x F(2,3)) has its own layout."""
+    if form != 5:
+        _need_diag("adain_conv3x3_wino_pack")
     w = _dev(w_oihw, "weight")
     cout, cin = w.shape[:2]
     sizer, packer = ((lib().adain_conv3x3_wino4_packed_floats, lib().adain_conv3x3_wino4_pack) if form == 5 else

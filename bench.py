@@ -61,8 +61,11 @@ import applied_image_processing_amd.synth as synth
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0           # same guide: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable by a float4 copy)
-# The product library always runs the F(4,3) x F(2,3) kernels; only the diagnostic build (ADAIN_HIP_LIB=libadain_hip_diag.so)
-# reads ADAIN_WINOGRAD=0 (direct implicit GEMM) / ADAIN_WINO_MH (F(2x2,3x3) forms) for A/B runs.
+# The product library always runs the F(4,3) x F(2,3) kernels.  `--diag-lib` (A/B runs only; the JSON line is labelled) loads the
+# diagnostic build instead, which reads ADAIN_WINOGRAD=0 (direct implicit GEMM) / ADAIN_WINO_MH (F(2x2,3x3) forms) and the tuning switches.
+if "--diag-lib" in sys.argv:
+    sys.argv.remove("--diag-lib")
+    rt.use_library(rt.DIAG_LIB_PATH)
 _DIAG_LIB = "diag" in os.path.basename(rt.LIB_PATH)
 WINOGRAD = not _DIAG_LIB or os.environ.get("ADAIN_WINOGRAD", "1") != "0"
 WINO_FORM = int(os.environ.get("ADAIN_WINO_MH", "5")) if _DIAG_LIB else 5
@@ -584,6 +587,7 @@ class Ctx:
 
 def base_result(args, ctx, value, ms, workload, parallelism, scaling):
     return {
+        **({"diagnostic_library": True} if _DIAG_LIB else {}),
         "metric": "stylized Mpixels/sec, AdaIN forward (encode content + encode style + AdaIN + decode)",
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,

@@ -37,33 +37,38 @@ extern "C" {
 
 typedef void* adain_stream_t; /* hipStream_t */
 
-int adain_abi_version(void);
-const char* adain_last_error(void);
+/* The shared library is built with -fvisibility=hidden: these entry points are all it exports. */
+#ifndef ADAIN_API
+#define ADAIN_API __attribute__((visibility("default")))
+#endif
+
+ADAIN_API int adain_abi_version(void);
+ADAIN_API const char* adain_last_error(void);
 
 /* ---- weights: pack a reference state_dict once (net.vgg / net.decoder, net.py:6-92) ----------------
  * w[i] / b[i] are the OIHW weight and bias tensors of the i-th conv in module order
  * (encoder: state_dict keys 0,2,5,9,12,16,19,22,25,29 ; decoder: 1,5,8,11,14,18,21,25,28).
  * `packed` receives MFMA-fragment-ordered weights + biases; its size is the *_floats query. */
-size_t adain_encoder_packed_floats(void);
-size_t adain_decoder_packed_floats(void);
-int adain_encoder_pack(const float* const* w_host_array_of_dev_ptrs, const float* const* b_host_array_of_dev_ptrs,
+ADAIN_API size_t adain_encoder_packed_floats(void);
+ADAIN_API size_t adain_decoder_packed_floats(void);
+ADAIN_API int adain_encoder_pack(const float* const* w_host_array_of_dev_ptrs, const float* const* b_host_array_of_dev_ptrs,
                        float* packed, adain_stream_t stream);
-int adain_decoder_pack(const float* const* w_host_array_of_dev_ptrs, const float* const* b_host_array_of_dev_ptrs,
+ADAIN_API int adain_decoder_pack(const float* const* w_host_array_of_dev_ptrs, const float* const* b_host_array_of_dev_ptrs,
                        float* packed, adain_stream_t stream);
 
 /* ---- encoder: vgg[:31](x), conv0 .. relu4_1 (net.py:38-69; test.py:57,63,76-77,185) -----------------
  * image NCHW [n][3][h][w] -> feat NHWC [n][hc][wc][512], hc = ceil(ceil(ceil(h/2)/2)/2) (same for w).
  * layer_events: optional host array of 11 hipEvent_t recorded before layer 0 and after each of the
  * 10 conv launches (profiling only; NULL in production). */
-void adain_encoded_size(int h, int w, int* hc, int* wc);
-size_t adain_encode_workspace_bytes(int n, int h, int w);
-int adain_encode(const float* image_nchw, float* feat_nhwc, const float* packed, void* workspace,
+ADAIN_API void adain_encoded_size(int h, int w, int* hc, int* wc);
+ADAIN_API size_t adain_encode_workspace_bytes(int n, int h, int w);
+ADAIN_API int adain_encode(const float* image_nchw, float* feat_nhwc, const float* packed, void* workspace,
                  size_t workspace_bytes, int n, int h, int w, void* const* layer_events, adain_stream_t stream);
 
 /* adain_encode on a decoded frame as the reference holds it before ToTensor (test.py:16-24, :190-204): image HWC uint8
  * [n][h][w][3].  The first layer's kernel applies ToTensor itself (float(v) / 255, correctly rounded), so the features are
  * bit-identical to adain_encode(ToTensor(image)) while the frame crosses PCIe and HBM as 3 bytes per pixel instead of 12. */
-int adain_encode_u8(const uint8_t* image_nhwc_u8, float* feat_nhwc, const float* packed, void* workspace,
+ADAIN_API int adain_encode_u8(const uint8_t* image_nhwc_u8, float* feat_nhwc, const float* packed, void* workspace,
                     size_t workspace_bytes, int n, int h, int w, void* const* layer_events, adain_stream_t stream);
 
 /* The same encoder over `count` (1..4) image batches of different sizes in ONE pass: the content batch and the style image
@@ -71,21 +76,21 @@ int adain_encode_u8(const uint8_t* image_nhwc_u8, float* feat_nhwc, const float*
  * per batch; every generic 3x3 layer is a single launch whose tile list covers all batches, so the small style-branch layers
  * ride in the content launches instead of under-filling the chip on their own.  images[i] NCHW [n[i]][3][h[i]][w[i]] ->
  * feats[i] NHWC.  The pointer arrays and n / h / w are HOST arrays.  layer_events as for adain_encode. */
-size_t adain_encode_multi_workspace_bytes(int count, const int* n, const int* h, const int* w);
-int adain_encode_multi(int count, const float* const* images_nchw, float* const* feats_nhwc, const int* n, const int* h,
+ADAIN_API size_t adain_encode_multi_workspace_bytes(int count, const int* n, const int* h, const int* w);
+ADAIN_API int adain_encode_multi(int count, const float* const* images_nchw, float* const* feats_nhwc, const int* n, const int* h,
                        const int* w, const float* packed, void* workspace, size_t workspace_bytes,
                        void* const* layer_events, adain_stream_t stream);
 
 /* ---- decoder: net.decoder(feat) (net.py:6-36; test.py:71,81) ----------------------------------------
  * feat NHWC [n][hc][wc][512] -> image NCHW [n][3][8hc][8wc].  layer_events: 10 events (before + 9 convs). */
-size_t adain_decode_workspace_bytes(int n, int hc, int wc);
-int adain_decode(const float* feat_nhwc, float* image_nchw, const float* packed, void* workspace,
+ADAIN_API size_t adain_decode_workspace_bytes(int n, int hc, int wc);
+ADAIN_API int adain_decode(const float* feat_nhwc, float* image_nchw, const float* packed, void* workspace,
                  size_t workspace_bytes, int n, int hc, int wc, void* const* layer_events, adain_stream_t stream);
 
 /* ---- calc_mean_std (function.py:4-12): per (n, c) mean and sqrt(unbiased var + eps) over h*w ---------
  * nhwc != 0: feat is [n][hw][c]; nhwc == 0: feat is [n][c][hw].  mean/std: [n][c]. */
-size_t adain_mean_std_workspace_bytes(int nhwc, int n, int c, int hw);
-int adain_mean_std(const float* feat, int nhwc, int n, int c, int hw, float eps, float* mean, float* std_out,
+ADAIN_API size_t adain_mean_std_workspace_bytes(int nhwc, int n, int c, int hw);
+ADAIN_API int adain_mean_std(const float* feat, int nhwc, int n, int c, int hw, float eps, float* mean, float* std_out,
                    void* workspace, size_t workspace_bytes, adain_stream_t stream);
 
 /* ---- adaptive_instance_normalization + blend (function.py:15-23; test.py:69-70, 79-80) -----------------
@@ -93,18 +98,18 @@ int adain_mean_std(const float* feat, int nhwc, int n, int c, int hw, float eps,
  *   alpha form: out = t*alpha + x*one_minus_alpha          (style_transfer_simple; plain AdaIN = 1, 0)
  *   pmap  form: out = t*(1 - P) + x*P, P [pmap_n][hw]      (style_transfer, depth-aware)
  * style_n and pmap_n are 1 (broadcast over the batch) or n. */
-int adain_blend_alpha(const float* content_feat, int nhwc, int n, int c, int hw, const float* c_mean,
+ADAIN_API int adain_blend_alpha(const float* content_feat, int nhwc, int n, int c, int hw, const float* c_mean,
                       const float* c_std, const float* s_mean, const float* s_std, int style_n, float alpha,
                       float one_minus_alpha, float* out, adain_stream_t stream);
-int adain_blend_pmap(const float* content_feat, int nhwc, int n, int c, int hw, const float* c_mean,
+ADAIN_API int adain_blend_pmap(const float* content_feat, int nhwc, int n, int c, int hw, const float* c_mean,
                      const float* c_std, const float* s_mean, const float* s_std, int style_n, const float* pmap,
                      int pmap_n, float* out, adain_stream_t stream);
 
 /* ---- compute_stylization_strength_map (test.py:119-150) ------------------------------------------------
  * depth [h0][w0] -> pmap [hc][wc]: bicubic resize, min-max normalise, minus mean, sigmoid(prominence*P),
  * clamp(max = 1 - offset); an exactly constant resized map gives zeros (test.py:141-143). */
-size_t adain_strength_map_workspace_bytes(int hc, int wc);
-int adain_strength_map(const float* depth, int h0, int w0, int hc, int wc, float offset, float prominence,
+ADAIN_API size_t adain_strength_map_workspace_bytes(int hc, int wc);
+ADAIN_API int adain_strength_map(const float* depth, int h0, int w0, int hc, int wc, float offset, float prominence,
                        float* pmap, void* workspace, size_t workspace_bytes, adain_stream_t stream);
 
 /* ---- content-mask composite of adain_inference (test.py:222-236) ---------------------------------------
@@ -112,27 +117,27 @@ int adain_strength_map(const float* depth, int h0, int w0, int hc, int wc, float
  * align_corners=False), nearest = F.interpolate(mode="nearest").
  * mask_composite: out = content*(1-m) + stylized*m on NCHW [n][c][hw]; mask [mask_n][mask_c][hw],
  * mask_c in {1, c}, mask_n in {1, n}. */
-int adain_resize_bilinear(const float* in, float* out, int planes, int hi, int wi, int ho, int wo,
+ADAIN_API int adain_resize_bilinear(const float* in, float* out, int planes, int hi, int wi, int ho, int wo,
                           adain_stream_t stream);
-int adain_resize_nearest(const float* in, float* out, int planes, int hi, int wi, int ho, int wo,
+ADAIN_API int adain_resize_nearest(const float* in, float* out, int planes, int hi, int wi, int ho, int wo,
                          adain_stream_t stream);
-int adain_mask_composite(const float* content, const float* stylized, const float* mask, int mask_c, int mask_n,
+ADAIN_API int adain_mask_composite(const float* content, const float* stylized, const float* mask, int mask_c, int mask_n,
                          float* out, int n, int c, int hw, adain_stream_t stream);
 
 /* ---- torchvision save_image quantiser (test.py:243-244): NCHW float -> NHWC u8, x*255+0.5 clamped ------ */
-int adain_quantize_u8(const float* image_nchw, uint8_t* out_nhwc, int n, int c, int h, int w,
+ADAIN_API int adain_quantize_u8(const float* image_nchw, uint8_t* out_nhwc, int n, int c, int h, int w,
                       adain_stream_t stream);
 
 /* ---- torchvision ToTensor (test.py:22): NHWC u8 [n][h][w][c] -> NCHW float [n][c][h][w], float(v) / 255 correctly rounded
  * (bit for bit `tensor.float() / 255`); what the mask composite needs of a frame that was uploaded as uint8 ------------------ */
-int adain_u8_to_f32(const uint8_t* in_nhwc, float* out_nchw, int n, int c, int h, int w, adain_stream_t stream);
+ADAIN_API int adain_u8_to_f32(const uint8_t* in_nhwc, float* out_nchw, int n, int c, int h, int w, adain_stream_t stream);
 
 /* ---- video post-pass (reference video/utils.py:89-105 warp_image + :223-229 blend_images) -------------------
  * HWC uint8 frames [h][w][c]; flow [2][h][w] (x then y displacement, as estimate_optical_flow returns it,
  * video/utils.py:75-86).  out = u8(clip((alpha*cur/255 + one_minus_alpha*warp(prev)/255)*255, 0, 255)), warp =
  * cv2.remap(INTER_LINEAR, BORDER_REFLECT) in OpenCV's uint8 fixed point (map rounded to 1/32 px, 2^15-scaled weights,
  * (sum + 2^14) >> 15).  The optical-flow estimate itself stays with the caller (OpenCV). */
-int adain_warp_blend_u8(const uint8_t* cur_u8, const uint8_t* prev_u8, const float* flow, uint8_t* out_u8, int h, int w,
+ADAIN_API int adain_warp_blend_u8(const uint8_t* cur_u8, const uint8_t* prev_u8, const float* flow, uint8_t* out_u8, int h, int w,
                         int c, float alpha, float one_minus_alpha, adain_stream_t stream);
 
 /* cv2.resize(frames_u8, (wo, ho), interpolation=cv2.INTER_AREA) of the same post-pass (reference video/utils.py:352-353) on
@@ -141,38 +146,24 @@ int adain_warp_blend_u8(const uint8_t* cur_u8, const uint8_t* prev_u8, const flo
  * scales use resizeArea_'s float tap tables in OpenCV's accumulation order.  With an axis enlarged OpenCV leaves that branch
  * and so does this call: the 11-bit fixed-point linear pass with "area mode" coefficients (an integer enlargement replicates
  * pixels). */
-int adain_resize_area_u8(const uint8_t* in_u8, uint8_t* out_u8, int n, int hi, int wi, int c, int ho, int wo,
+ADAIN_API int adain_resize_area_u8(const uint8_t* in_u8, uint8_t* out_u8, int n, int hi, int wi, int c, int ho, int wo,
                          adain_stream_t stream);
 
 /* ---- layout changes at the boundary ([n][c][hw] <-> [n][hw][c]) ------------------------------------------ */
-int adain_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, adain_stream_t stream);
-int adain_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, adain_stream_t stream);
+ADAIN_API int adain_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, adain_stream_t stream);
+ADAIN_API int adain_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, adain_stream_t stream);
 
-/* ---- single layers (unit tests, profiling, tuning) ------------------------------------------------------
- * conv3x3: ReflectionPad2d(1) + Conv2d(cin, cout, 3) [+ ReLU] on NHWC, with the pool / upsample of the
- * producer fused into the input gather (src_mode) and/or the max-pool behind this layer fused into the
- * epilogue (pool_out != 0: out is [n][ceil(h/2)][ceil(w/2)][cout]).  (h, w) = conv output size before any
- * output pool; (hs, ws) = source size.  cin % 16 == 0, cout % 64 == 0.  variant < 0 selects the tile shape
- * automatically; 0..7 force one (csrc/conv.hip, launch_variant; 5 and 6 are the persistent kernels). */
-size_t adain_conv3x3_packed_floats(int cin, int cout);
-int adain_conv3x3_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
-int adain_conv3x3(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,
-                  int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out, int variant,
-                  adain_stream_t stream);
-
-/* Winograd forms of the same layer (adain_encode / adain_decode use form 5 for every generic 3x3 layer).
- *   form 5: F(4,3) x F(2,3), 4 x 2 output tiles, 3 multiplies per output instead of 9 (fp32 rounding error ~5x the direct
- *           form's, ~1e-6 relative per layer); its own packing, 24 floats per (cin, cout) pair (adain_conv3x3_wino4_pack);
- *           cin % 16 == 0, cout % 32 == 0; persistent kernel when the launch has >= 2 tiles per resident workgroup;
- *   forms 1-4: F(2x2,3x3), 4 multiplies per output; packing of 16 floats per pair (adain_conv3x3_wino_pack); cout % 64 == 0;
- *           3: A operand transformed in registers (cin % 16 == 0), 4: its persistent form (cin >= 32), 1 / 2: transformed
- *           input staged in LDS (cin % 8 == 0), 1 or 2 32-tile M-tiles per workgroup.
- * src_mode DIRECT or UP2X; relu / pool_out as for adain_conv3x3. */
-size_t adain_conv3x3_wino_packed_floats(int cin, int cout);
-int adain_conv3x3_wino_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
-size_t adain_conv3x3_wino4_packed_floats(int cin, int cout);
-int adain_conv3x3_wino4_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
-int adain_conv3x3_wino(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,
+/* ---- one generic 3x3 layer in the form the schedules run (unit tests, profiling) ---------------------------------
+ * ReflectionPad2d(1) + Conv2d(cin, cout, 3) [+ ReLU] on NHWC as Winograd F(4,3) x F(2,3): 4 x 2 output tiles, 3 multiplies per
+ * output instead of 9 (fp32 rounding error ~5x the direct form's, ~1e-6 relative per layer).  The nearest-2x upsample of the
+ * producer may be fused into the input gather (src_mode ADAIN_SRC_UP2X) and the ceil-mode max-pool behind the layer into the
+ * epilogue (pool_out != 0: out is [n][ceil(h/2)][ceil(w/2)][cout]).  (h, w) = conv output size before any output pool;
+ * (hs, ws) = source size.  Weights packed by adain_conv3x3_wino4_pack, 24 floats per (cin, cout) pair; cin % 16 == 0,
+ * cout % 32 == 0; persistent kernel when the launch has >= 2 tiles per resident workgroup.  `form` must be 5 (the other forms -
+ * F(2x2,3x3) and the direct implicit GEMM - live in the diagnostic library only, include/adain_hip_diag.h). */
+ADAIN_API size_t adain_conv3x3_wino4_packed_floats(int cin, int cout);
+ADAIN_API int adain_conv3x3_wino4_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
+ADAIN_API int adain_conv3x3_wino(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,
                        int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out, int form,
                        adain_stream_t stream);
 

@@ -251,7 +251,7 @@ def test_depth_provider_hook_and_cli_pixels(rt, weights, tmp_path):
 
 # ---- Winograd F(4,3) x F(2,3) where its transforms cancel: large DC inputs, zero-sum filters ------------------------------------------
 @pytest.mark.parametrize("cin,cout,hw", [(64, 64, (40, 72)), (256, 256, (24, 40)), (512, 256, (16, 24))])
-def test_winograd_large_dc_zero_sum_filters(rt, cin, cout, hw):
+def test_winograd_large_dc_zero_sum_filters(rt, diag_lib, cin, cout, hw):
     """Post-ReLU-like inputs (non-negative, mean 50, sigma 1) against filters whose nine taps sum to zero: the exact result
     is O(1) while the F(4,3) input transform (coefficients up to 5) works on values of magnitude 50 x 10.  The error bound
     asserted is the path's per-layer tolerance (2e-4 absolute + relative) scaled by nothing: it must hold as is."""

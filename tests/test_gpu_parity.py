@@ -59,7 +59,7 @@ def psnr01(a, b):
 # ---- single conv layers, all gather modes, ragged tiles -----------------------------------------------
 @pytest.mark.parametrize("mode", ["direct", "up", "pool"])
 @pytest.mark.parametrize("shape", [(1, 64, 64, 9, 37), (2, 64, 128, 16, 32), (1, 128, 256, 21, 70), (1, 512, 256, 5, 6)])
-def test_conv3x3_vs_oracle(rt, mode, shape):
+def test_conv3x3_vs_oracle(rt, mode, shape, diag_lib):
     n, cin, cout, hs, ws = shape
     x = T(synth.uniform_sym(100 + cin, (n, cin, hs, ws), 1.0))
     w = T(synth.uniform_sym(200 + cout, (cout, cin, 3, 3), (6.0 / (9 * cin)) ** 0.5))
@@ -116,7 +116,7 @@ def test_conv3x3_f43xf23_random_layers(rt):
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("shape", [(1, 64, 128, 19, 45), (2, 128, 128, 8, 33), (3, 64, 64, 70, 100)])
-def test_conv3x3_tile_variants_and_fused_output_pool(rt, variant, shape):
+def test_conv3x3_tile_variants_and_fused_output_pool(rt, variant, shape, diag_lib):
     n, cin, cout, h, w = shape
     if variant == 1 and cout % 128:
         pytest.skip("variant 1 needs cout % 128 == 0")
@@ -139,7 +139,7 @@ def test_conv3x3_tile_variants_and_fused_output_pool(rt, variant, shape):
 @pytest.mark.parametrize("m_tiles", [2, 1, 3, 4, 5])
 @pytest.mark.parametrize("mode", ["direct", "up"])
 @pytest.mark.parametrize("shape", [(1, 128, 128, 16, 32), (2, 128, 64, 9, 37), (1, 256, 128, 21, 70), (1, 512, 256, 5, 6), (1, 64, 64, 8, 8)])
-def test_conv3x3_winograd_vs_oracle(rt, mode, shape, m_tiles):
+def test_conv3x3_winograd_vs_oracle(rt, mode, shape, m_tiles, diag_lib):
     """Winograd F(2x2,3x3) kernel against torch's direct convolution (same tolerance as the direct kernel)."""
     n, cin, cout, hs, ws = shape
     x = T(synth.uniform_sym(400 + cin, (n, cin, hs, ws), 1.0))
@@ -158,7 +158,7 @@ def test_conv3x3_winograd_vs_oracle(rt, mode, shape, m_tiles):
 
 @pytest.mark.parametrize("mode,shape", [("direct", (1, 64, 128, 250, 203)), ("direct", (2, 32, 64, 131, 257)), ("up", (1, 64, 64, 121, 150)),
                                         ("direct", (3, 128, 64, 6, 40))])
-def test_conv3x3_winograd_persistent_many_tiles(rt, mode, shape):
+def test_conv3x3_winograd_persistent_many_tiles(rt, mode, shape, diag_lib):
     """The persistent form on grids where a workgroup walks several tiles (more tiles than 2 x CUs), ragged edges, several
     images and channel tiles: every tile hand-over (prefetched halo, weight ring wrap, LDS reuse) is exercised."""
     n, cin, cout, hs, ws = shape
@@ -222,7 +222,7 @@ def test_conv3x3_winograd_f43_persistent_tile_lists(rt, mode, shape):
           F.max_pool2d(F.relu(pre), 2, 2, 0, ceil_mode=True))
 
 
-def test_conv3x3_rejects_bad_shapes(rt):
+def test_conv3x3_rejects_bad_shapes(rt, diag_lib):
     x = torch.zeros(1, 4, 4, 24, device="cuda")
     with pytest.raises(rt.AdainHipError):
         rt.conv3x3(x, torch.zeros(24 * 64 * 9, device="cuda"), torch.zeros(64, device="cuda"), 64)
@@ -259,6 +259,31 @@ def test_case_a_golden(rt, nets, weights):
         assert tuple(out.shape) == (1, 3, 64, 64)
         close(out, g[key], 5e-4, 5e-4)
         assert psnr01(out, T(g[key])) >= 60.0
+
+
+def test_case_f_config1_reference_sample_images(rt, nets):
+    """BASELINE config 1 on the GPU: the reference's own sample images (resized to 256; uint8 data in the fixture) through
+    style_transfer_simple - from the float tensors as run_depth.py / adain_inference build them, and from the uint8 frames with
+    ToTensor inside the first layer's kernel - against the reference's output."""
+    vgg, dec = nets
+    g = golden("case_f.npz")
+    from applied_image_processing_amd.AdaIN import test as t
+
+    cu8, su8 = T(g["content_u8"]).cuda(), T(g["style_u8"]).cuda()
+    c = cu8.permute(2, 0, 1).float().div(255).unsqueeze(0).contiguous()
+    s = su8.permute(2, 0, 1).float().div(255).unsqueeze(0).contiguous()
+    out = t.style_transfer_simple(vgg, dec, c, s, 0.5)
+    assert tuple(out.shape) == (1, 3, 256, 256)
+    close(out, g["out"], 5e-4, 5e-4)
+    assert psnr01(out, T(g["out"])) >= 60.0
+    rel = float((out.cpu() - T(g["out"])).norm() / T(g["out"]).norm())
+    assert rel < 1e-4, rel
+    # the same forward from the decoded frames (what the job drivers upload)
+    from applied_image_processing_amd.engine import AdaINEngine
+
+    eng = AdaINEngine(vgg.state_dict(), dec.state_dict(), "cuda:0")
+    eng.set_style(s)
+    assert torch.equal(eng.stylize(cu8.unsqueeze(0), 0.5), out)
 
 
 def test_case_b_odd_depth_mask_golden(rt, nets):
@@ -570,7 +595,7 @@ def test_called_from_a_background_thread(rt, nets):
         try:
             got[key] = t.style_transfer_simple(vgg, dec, c, s, 0.6).cpu()
             try:
-                rt.conv3x3(torch.zeros(1, 8, 8, 60, device="cuda"), torch.zeros(8, device="cuda"), torch.zeros(64, device="cuda"), 64)
+                rt.conv3x3_wino(torch.zeros(1, 8, 8, 60, device="cuda"), torch.zeros(8, device="cuda"), torch.zeros(64, device="cuda"), 64, m_tiles=5)
             except rt.AdainHipError as e:
                 errs[key] = str(e)
         except Exception as e:      # surfaced by the asserts below

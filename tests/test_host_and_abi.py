@@ -25,22 +25,58 @@ def _lib_built():
     return rt.lib()
 
 
-def test_every_declared_symbol_is_exported_and_bound():
-    header = open(os.path.join(ROOT, "include", "adain_hip.h")).read()
+def _declared(header_name):
+    header = open(os.path.join(ROOT, "include", header_name)).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    declared = sorted(set(re.findall(r"\b(adain_[a-z0-9_]+)\s*\(", header)))
+    return sorted(set(re.findall(r"\b(adain_[a-z0-9_]+)\s*\(", header)))
+
+
+def _exported_functions(path):
+    """Names of the defined dynamic symbols of type T (code) of a shared library."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T")
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    declared = _declared("adain_hip.h")
     assert len(declared) >= 25
     lib = _lib_built()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in adain_hip.h but not exported"
         assert name in rt.SIGNATURES, f"{name} has no ctypes signature in runtime.py"
     assert sorted(rt.SIGNATURES) == declared
+    # -fvisibility=hidden: the C ABI is ALL the code the product library exports (no C++ launchers, no helper functions)
+    assert _exported_functions(rt.LIB_PATH) == declared
+    assert not hasattr(lib, "adain_conv3x3") and not hasattr(lib, "adain_debug_set_conv_stamp_buffer")
     assert lib.adain_abi_version() == 1
     assert lib.adain_encoder_packed_floats() > 3_500_000 and lib.adain_decoder_packed_floats() > 3_500_000
     hc, wc = ctypes.c_int(), ctypes.c_int()
     lib.adain_encoded_size(45, 67, ctypes.byref(hc), ctypes.byref(wc))
     assert (hc.value, wc.value) == (6, 9) == arch.encoded_size(45, 67)
     assert lib.adain_encode_workspace_bytes(1, 1024, 1024) == (64 + 16) * 1024 * 1024 * 4   # A: conv1_1 out, B: pooled conv1_2 out
+
+
+def test_diagnostic_library_exports_both_headers(diag_lib):
+    both = sorted(set(_declared("adain_hip.h")) | set(_declared("adain_hip_diag.h")))
+    assert _exported_functions(diag_lib.LIB_PATH) == both
+    assert sorted(set(diag_lib.SIGNATURES) | set(diag_lib.DIAG_SIGNATURES)) == both
+    assert diag_lib.is_diag() and diag_lib.lib().adain_abi_version() == 1
+
+
+def test_product_library_ignores_the_environment(monkeypatch):
+    """ADAIN_HIP_LIB (round 2's switch) no longer redirects the product runtime; the older kernel families say where they live."""
+    import importlib
+
+    monkeypatch.setenv("ADAIN_HIP_LIB", "/nonexistent/libother.so")
+    fresh = importlib.reload(rt)
+    try:
+        assert fresh.LIB_PATH.endswith("libadain_hip.so") and not fresh.is_diag()
+        with pytest.raises(fresh.AdainHipError, match="diagnostic library"):
+            fresh.conv3x3_pack(torch.zeros(64, 64, 3, 3))
+    finally:
+        importlib.reload(rt)
 
 
 def test_no_cpu_fallback():

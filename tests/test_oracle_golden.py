@@ -72,6 +72,20 @@ def test_case_c_batch(weights):
         close(O.style_transfer_simple(vgg, dec, c, s, 0.7), g["out_a07"], 1e-4, 1e-4)
 
 
+def test_case_f_config1_reference_sample_images(weights):
+    """BASELINE config 1 (run_depth.py:47 on the reference's brad_pitt.jpg + brushstrokes.jpg at 256): the resized uint8 images
+    are data in the fixture, the expected output comes from the reference's own style_transfer_simple."""
+    vgg, dec = weights
+    g = golden("case_f.npz")
+    assert g["content_u8"].shape == (256, 256, 3) and g["style_u8"].shape == (256, 341, 3)      # SURVEY.md 8(c): 256 x 256, 341 x 256
+    c = T(g["content_u8"].transpose(2, 0, 1)).float().div(255).unsqueeze(0)
+    s = T(g["style_u8"].transpose(2, 0, 1)).float().div(255).unsqueeze(0)
+    with torch.no_grad():
+        out = O.style_transfer_simple(vgg, dec, c, s, 0.5)
+    assert tuple(out.shape) == (1, 3, 256, 256)
+    close(out, g["out"], 1e-4, 1e-4)
+
+
 def test_case_d_coral_host_path():
     """coral (function.py:41-67) is host-side in the reference and here; pinned to the reference's own output."""
     from applied_image_processing_amd.AdaIN.function import coral

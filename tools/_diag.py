@@ -10,4 +10,6 @@ if ROOT not in sys.path:
 _lib = os.path.join(ROOT, "applied-image-processing_amd", "libadain_hip_diag.so")
 if not os.path.exists(_lib):
     raise SystemExit(f"{_lib} is missing: build it with `python applied-image-processing_amd/build.py --diag`")
-os.environ.setdefault("ADAIN_HIP_LIB", _lib)
+import applied_image_processing_amd.runtime as _rt  # noqa: E402
+
+_rt.use_library(_lib)
