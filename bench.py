@@ -648,7 +648,8 @@ def main_job(args, ctx):
         pcie = {"value": round(n_total * h * w / 1e6 / (pdt / args.steps), 3), "unit": "Mpixels/s", "ms_per_step": round(pdt / args.steps * 1e3, 3),
                 "what": "the same job with its frames (and masks) in pageable host memory: pinned staging + uint8 upload on a copy stream "
                         "behind the kernels, ToTensor on the device, the gathered uint8 result copied back to pinned host memory",
-                "h2d_bytes_rank0": int(pinfo["h2d_bytes"]), "fetch_s_rank0": round(float(pinfo["fetch_s"]), 4),
+                "h2d_bytes_rank0": int(pinfo["h2d_bytes"]), "d2h_bytes_rank0": int(pinfo.get("d2h_bytes", 0)),
+                "rank0": {k: round(float(pinfo[k]), 4) for k in ("compute_s", "gather_s", "enqueue_s", "fetch_s")},
                 "bit_identical_to_resident": True}
 
     if rank == 0:
