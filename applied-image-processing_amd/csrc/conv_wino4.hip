@@ -223,24 +223,34 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     const rsrc_t wsr = make_rsrc(a.wpk, (unsigned)a.cin * a.cout * 96u);
 
     // ---- raw halo staging: 340 pixels x 4 quads over 256 threads x 6 items ---------------------------------------------------
+    // Per-lane byte offsets of the six staging items + a per-tile SCALAR base (the buffer load's soffset operand).  A tile whose
+    // 10 x 34 halo lies inside the image needs no reflection (92 % of the tiles at 1024 x 1024), and then item k of a lane sits at
+    // tile base + an offset that depends only on the lane and the segment's row pitch: the six registers are computed once per
+    // segment (roff_seg remembers for which) and an interior tile costs scalar arithmetic only - round 2 recomputed them per
+    // tile, 78 vector instructions of the ~560 a tile spends outside its main loop (they cost matrix-pipe time: DESIGN.md 4).
+    // Tile origins are multiples of 8 / 32, so the nearest-2x source index splits the same way: (x0 + hx - 1) >> 1 =
+    // (x0 / 2 - 1) + ((hx + 1) >> 1).  Tiles at the image border take the general path (reflection, base 0).
     int roff[W4_RITEMS];
-    auto halo_offsets = [&](int x0, int y0, int H, int W, int Ws) {
+    int tbase = 0, roff_seg = -1;
+    auto halo_offsets = [&](int x0, int y0, int H, int W, int Ws, int sg) {
         const int t = PERSIST ? (lane_now() | (wj << 6)) : tid;        // persistent: recomputed per tile, nothing hoisted
-        // a tile whose 10 x 34 halo lies inside the image needs no reflection (92 % of the tiles at 1024 x 1024): the uniform
-        // branch saves 14 of the 27 vector instructions per item, 84 per tile and wave
         const bool interior = PERSIST && y0 >= 1 && y0 + W4_HALO_H - 1 <= H && x0 >= 1 && x0 + W4_HALO_W - 1 <= W;
         [[maybe_unused]] const int r0 = src_row0(y0);  // BIG: rows are counted from the tile's source descriptor
         if (interior) {
+            if (roff_seg != sg) {
 #pragma unroll
-            for (int k = 0; k < W4_RITEMS; ++k) {
-                const int idx = t + k * 256;
-                const int hp = min(idx >> 2, W4_HALO - 1), q = idx & 3;
-                const int hy = (hp * 241) >> 13, hx = hp - hy * W4_HALO_W;          // hp / 34 for hp < 400
-                int y = y0 + hy - 1, x = x0 + hx - 1;
-                if (MODE == SRC_UP2X) { y >>= 1; x >>= 1; }
-                if constexpr (BIG) y = MODE == SRC_UP2X ? y - r0 : hy;
-                roff[k] = ((y * Ws + x) * a.cin + q * 4) * 4;
+                for (int k = 0; k < W4_RITEMS; ++k) {
+                    const int idx = t + k * 256;
+                    const int hp = min(idx >> 2, W4_HALO - 1), q = idx & 3;
+                    const int hy = (hp * 241) >> 13, hx = hp - hy * W4_HALO_W;          // hp / 34 for hp < 400
+                    const int yc = MODE == SRC_UP2X ? (hy + 1) >> 1 : hy, xc = MODE == SRC_UP2X ? (hx + 1) >> 1 : hx;
+                    roff[k] = ((yc * Ws + xc) * a.cin + q * 4) * 4;
+                }
+                roff_seg = sg;
             }
+            // source pixel of the halo's top-left corner; BIG: the tile's descriptor already starts at that row
+            const int by = BIG ? 0 : (MODE == SRC_UP2X ? (y0 >> 1) - 1 : y0 - 1), bx = MODE == SRC_UP2X ? (x0 >> 1) - 1 : x0 - 1;
+            tbase = ((by * Ws + bx) * a.cin) * 4;
         } else {
 #pragma unroll
             for (int k = 0; k < W4_RITEMS; ++k) {
@@ -252,13 +262,15 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 if constexpr (BIG) y -= r0;
                 roff[k] = ((y * Ws + x) * a.cin + q * 4) * 4;
             }
+            roff_seg = -1;
+            tbase = 0;
         }
     };
-    halo_offsets(tx0, ty0, gH, gW, gWs);
+    halo_offsets(tx0, ty0, gH, gW, gWs, seg);
     f32x4 rawreg[W4_RITEMS];
     auto raw_load = [&](int soff) {
 #pragma unroll
-        for (int k = 0; k < W4_RITEMS; ++k) rawreg[k] = buf_load4(src, roff[k], soff);
+        for (int k = 0; k < W4_RITEMS; ++k) rawreg[k] = buf_load4(src, roff[k], tbase + soff);
     };
     // LDS address (in floats) of staging item k of this thread: pixel (t >> 2) + 64 k of the halo, quad t & 3; depends on the
     // thread only, computed once
@@ -503,7 +515,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 // ---- halo loads two stages ahead, in the first two thirds of the chunk (regions 5, 7, 9, 11, 13, 15) ----
                 if constexpr (ld && DIAG != 10 && DIAG != 14 && b == 1 && h >= 5 && h <= 15) {      // DIAG 10: timing-only, no halo loads (stale stores)
                     constexpr int k = (h - 5) / 2;
-                    rawreg[k] = buf_load4(src, roff[k], raw_soff);
+                    rawreg[k] = buf_load4(src, roff[k], tbase + raw_soff);
                 }
                 // ---- input transform of the next chunk ----
                 if constexpr (do_xf && DIAG != 5) {
@@ -609,7 +621,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 // nst-3, or by the tile's entry code when nst == 2) the offsets switch to the next tile (loop tail, so that no
                 // branch splits the two chunks of a stage)
                 auto next_halo = [&]() {
-                    halo_offsets(ntx0, nty0, m.s[nseg].H, m.s[nseg].W, m.s[nseg].Ws);
+                    halo_offsets(ntx0, nty0, m.s[nseg].H, m.s[nseg].W, m.s[nseg].Ws, nseg);
                     src = src_of(m.s[nseg].in, m.s[nseg].Hs, m.s[nseg].Ws, nimg, nty0);
                 };
                 if (nst == 2) next_halo();

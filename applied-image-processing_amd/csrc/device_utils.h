@@ -11,9 +11,12 @@ __device__ __forceinline__ int reflect1(int v, int n) {
     return v >= n ? 2 * n - 2 - v : v;
 }
 
+// element-wise max as ONE v_med3_f32 per element: max(a, b) = med3(a, b, +inf).  fmaxf costs three instructions here (a
+// canonicalising v_max of each operand in front of the real one), and beside MFMAs every vector instruction counts.
 __device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) {
     f32x4 r;
-    r.x = fmaxf(a.x, b.x); r.y = fmaxf(a.y, b.y); r.z = fmaxf(a.z, b.z); r.w = fmaxf(a.w, b.w);
+    r.x = __builtin_amdgcn_fmed3f(a.x, b.x, __builtin_inff()); r.y = __builtin_amdgcn_fmed3f(a.y, b.y, __builtin_inff());
+    r.z = __builtin_amdgcn_fmed3f(a.z, b.z, __builtin_inff()); r.w = __builtin_amdgcn_fmed3f(a.w, b.w, __builtin_inff());
     return r;
 }
 

@@ -66,6 +66,11 @@ PEAK_HBM_GBS = 8000.0           # same guide: HBM3E 8.0 TB/s spec (about 6.3 TB/
 if "--diag-lib" in sys.argv:
     sys.argv.remove("--diag-lib")
     rt.use_library(rt.DIAG_LIB_PATH)
+if "--lib" in sys.argv:                  # same-box A/B against another build of the product library (the JSON line is labelled)
+    _i = sys.argv.index("--lib")
+    rt.use_library(os.path.abspath(sys.argv[_i + 1]))
+    del sys.argv[_i:_i + 2]
+_OTHER_LIB = os.path.basename(rt.LIB_PATH) if os.path.basename(rt.LIB_PATH) != "libadain_hip.so" else None
 _DIAG_LIB = "diag" in os.path.basename(rt.LIB_PATH)
 WINOGRAD = not _DIAG_LIB or os.environ.get("ADAIN_WINOGRAD", "1") != "0"
 WINO_FORM = int(os.environ.get("ADAIN_WINO_MH", "5")) if _DIAG_LIB else 5
@@ -587,7 +592,7 @@ class Ctx:
 
 def base_result(args, ctx, value, ms, workload, parallelism, scaling):
     return {
-        **({"diagnostic_library": True} if _DIAG_LIB else {}),
+        **({"diagnostic_library": True} if _DIAG_LIB else {}), **({"library": _OTHER_LIB} if _OTHER_LIB else {}),
         "metric": "stylized Mpixels/sec, AdaIN forward (encode content + encode style + AdaIN + decode)",
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
