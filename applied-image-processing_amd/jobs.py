@@ -117,6 +117,9 @@ class FrameFeeder:
         self.stop = threading.Event()
         self.h2d_bytes = 0
         self.fetch_s = 0.0
+        # where the worker thread's time goes (seconds): waiting for a free slot (= the consumer is the bottleneck, as it should
+        # be), waiting for a slot's previous upload to leave its pinned buffer, copying frames into pinned memory
+        self.stats = {"wait_slot_s": 0.0, "wait_h2d_s": 0.0, "stage_s": 0.0, "batches": 0}
         if self.cuda:
             self.copy_stream = torch.cuda.Stream(self.device)
             self.compute_stream = torch.cuda.current_stream(self.device)
@@ -203,8 +206,12 @@ class FrameFeeder:
                     return
                 t0 = time.perf_counter()
                 depth, mask = self._extras(i, j)
-                self.fetch_s += time.perf_counter() - t0
+                t1 = time.perf_counter()
+                self.fetch_s += t1 - t0
                 self.free.acquire()
+                t2 = time.perf_counter()
+                self.stats["wait_slot_s"] += t2 - t1
+                self.stats["batches"] += 1
                 if self.stop.is_set():
                     return
                 s = b % self.nslots
@@ -216,6 +223,8 @@ class FrameFeeder:
                 else:
                     if self.h2d_done[s] is not None:
                         self.h2d_done[s].synchronize()                   # the slot's previous uploads have left its pinned buffers
+                    t3 = time.perf_counter()
+                    self.stats["wait_h2d_s"] += t3 - t2
                     with torch.cuda.stream(self.copy_stream):
                         if self.consumed[s] is not None:
                             self.copy_stream.wait_event(self.consumed[s])      # the kernels that read this slot have finished
@@ -247,6 +256,7 @@ class FrameFeeder:
                             ready = torch.cuda.Event()
                             ready.record(self.copy_stream)
                             self.h2d_done[s] = ready
+                    self.stats["stage_s"] += time.perf_counter() - t3
                     if content is None:
                         content = items                                  # list of device tensors
                 self.q.put(_Batch(i, j, content, depth, mask, ready, s))
@@ -521,6 +531,7 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
         feeder.close()
     info["h2d_bytes"] = feeder.h2d_bytes
     info["fetch_s"] = feeder.fetch_s
+    info["feeder"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in feeder.stats.items()}
     m1 = _mark(engine)
     info["enqueue_s"] = time.perf_counter() - t_host0      # host time to fetch, upload and launch the whole block
 

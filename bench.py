@@ -654,7 +654,7 @@ def main_job(args, ctx):
                 "what": "the same job with its frames (and masks) in pageable host memory: pinned staging + uint8 upload on a copy stream "
                         "behind the kernels, ToTensor on the device, the gathered uint8 result copied back to pinned host memory",
                 "h2d_bytes_rank0": int(pinfo["h2d_bytes"]), "d2h_bytes_rank0": int(pinfo.get("d2h_bytes", 0)),
-                "rank0": {k: round(float(pinfo[k]), 4) for k in ("compute_s", "gather_s", "enqueue_s", "fetch_s")},
+                "rank0": {k: round(float(pinfo[k]), 4) for k in ("compute_s", "gather_s", "enqueue_s", "fetch_s")}, "feeder_rank0": pinfo.get("feeder"),
                 "bit_identical_to_resident": True}
 
     if rank == 0:
