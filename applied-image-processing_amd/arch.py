@@ -112,3 +112,14 @@ def conv_flops_decoder(hc, wc):
             h, w = 2 * h, 2 * w
         total += 2 * h * w * L["cin"] * L["cout"] * L["k"] * L["k"]
     return total
+
+
+def wino4_geometry(sizes):
+    """Tile geometry the F(4,3) x F(2,3) launcher picks for a launch over feature maps ``sizes`` = [(n, h, w), ...] (the segments of
+    one launch): 0 = 8 x 32 output pixels per workgroup tile, 1 = 16 x 16 - the one that needs fewer tiles, the default keeping
+    near-ties (mirrors ``pick_geo`` in csrc/conv_wino4.hip; tests use it to know which layout a shape exercises)."""
+    def tiles(th, tw):
+        return sum(n * (-(-h // th)) * (-(-w // tw)) for n, h, w in sizes)
+
+    t0, t1 = tiles(8, 32), tiles(16, 16)
+    return 1 if t1 * 101 < t0 * 100 else 0

@@ -39,25 +39,44 @@ namespace {
 static_assert(W4_GROUP == 1 || W4_GROUP == 8, "the burst schedule is laid out for groups of 8 (one pair of row positions)");
 constexpr int W4_KR = 16;                    // channels per raw stage = 2 chunks of 8
 constexpr int W4_RSTR = W4_KR + 4;           // floats per halo pixel (80 B = 5 quads: an odd number of 16-byte bank quads)
-constexpr int W4_HALO_W = 34, W4_HALO_H = 10;
-constexpr int W4_HALO = W4_HALO_H * W4_HALO_W;        // 340 pixels
-constexpr int W4_RITEMS = 6;                           // 340 x 4 quads over 256 threads
+constexpr int W4_RITEMS = 6;                 // staging items per thread: at most 340 halo pixels x 4 quads over 256 threads
+// Tile geometry (template parameter GEO): the 32 Winograd tiles of a workgroup sit either 2 x 16 (GEO 0: 8 x 32 output pixels, a
+// 10 x 34 halo - the tuned default) or 4 x 8 (GEO 1: 16 x 16 output pixels, an 18 x 18 halo).  One kernel, two layouts: the
+// launcher picks per layer the one that pads the feature map less (W = 400 pads to 416 with 32-wide tiles but not with
+// 16-wide ones; the reference's own video frames, 256 x 456, give maps 228 / 114 / 57 wide).
+//
 // LDS image of the raw halo, DE-INTERLEAVED by column parity: plane E holds the even halo columns, plane O the odd ones, each
-// [10 rows][17 columns] pixels of 20 floats.  The tiles of a workgroup sit 2 pixels apart, i.e. 1 plane pixel = 5 quads: the 16
-// lanes that one LDS cycle of a ds_read_b128 serves ({0-3,12-15,20-27} ..., MI355X_MICROARCH.md, LDS) then read 16 different
-// quads of the 64 banks.  In one interleaved image (round 1: [10][34] pixels) neighbouring tiles are 10 quads apart and every
-// patch read was a two-way bank conflict (SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE).  Row stride 88 quads (17 x 5 + 3):
-// the second tile row, 4 halo rows down, lands on the same quads modulo 16 as the first, so the columns 4-11 of one row and
-// 0-3 / 12-15 of the other (the hardware's lane groups) still cover all 16.  Plane O starts 4 quads (mod 8) after plane E: the
-// two neighbouring pixels that one 8-lane group of a staging ds_write_b128 stores cover all 32 banks.
-constexpr int W4_PROW = 17 * W4_RSTR + 12;             // 352 floats per plane row
-constexpr int W4_PLANE = W4_HALO_H * W4_PROW + 16;     // 3536 floats per plane
-constexpr int W4_TAIL = 2 * W4_PLANE;                  // staging items past the halo (44 pixels) land here, never read
-constexpr int W4_RBUF = 8192;                          // 2 planes + tail = 7952 floats, rounded: two buffers = the exchange area
+// [HALO_H rows][HALO_W / 2 columns] pixels of 20 floats.  The tiles of a workgroup sit 2 pixels apart, i.e. 1 plane pixel = 5
+// quads: the 16 lanes that one LDS cycle of a ds_read_b128 serves ({0-3,12-15,20-27} ..., MI355X_MICROARCH.md, LDS) must read
+// 16 different quads of the 64 banks.  In one interleaved image (round 1: [10][34] pixels) neighbouring tiles are 10 quads apart
+// and every patch read was a two-way bank conflict (SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE).
+//   GEO 0: lane li = tile (row li >> 4, column li & 15).  Row stride 88 quads (17 x 5 + 3): the second tile row, 4 halo rows
+//          down, lands on the same quads modulo 16 as the first, so the columns 4-11 of one row and 0-3 / 12-15 of the other
+//          (the hardware's lane groups) still cover all 16.
+//   GEO 1: lane li = tile (row li >> 3, column li & 7).  A lane group reads columns 0-3 of tile rows 0 and 3 and columns 4-7 of
+//          rows 1 and 2 (or the complement): columns 0-3 sit on quads {0,5,10,15}, columns 4-7 on {4,9,14,3} (mod 16), and the
+//          two sets together with their shifts by 8 cover all 16 - so tile rows 1 and 3 must be shifted by 8 quads and row 2 by
+//          0 (mod 16): 4 S = 8, 8 S = 0, 12 S = 8 (mod 16) for a row stride of S quads, i.e. S = 2 (mod 4): 46 = 9 x 5 + 1.
+// Plane O starts 4 quads (mod 8) after plane E: the two neighbouring pixels that one 8-lane group of a staging ds_write_b128
+// stores cover all 32 banks.
+template <int GEO>
+struct W4G {
+    static constexpr int TROWS_LOG = GEO == 0 ? 1 : 2;             // Winograd-tile rows of a workgroup = 2 / 4
+    static constexpr int TCOLS_LOG = 5 - TROWS_LOG;                // Winograd-tile columns = 16 / 8
+    static constexpr int TILE_H = 4 << TROWS_LOG, TILE_W = 2 << TCOLS_LOG;        // output pixels: 8 x 32 / 16 x 16
+    static constexpr int HALO_H = TILE_H + 2, HALO_W = TILE_W + 2;
+    static constexpr int HALO = HALO_H * HALO_W;                   // 340 / 324 pixels
+    static constexpr int PROW = (HALO_W / 2) * W4_RSTR + (GEO == 0 ? 12 : 4);      // 352 / 184 floats per plane row
+    static constexpr int PLANE = HALO_H * PROW + (GEO == 0 ? 16 : 0);              // 3536 / 3312 floats per plane
+    static constexpr int TAIL = 2 * PLANE;                         // staging items past the halo land here, never read
+    static_assert(TAIL + (W4_RITEMS * 64 - HALO) * W4_RSTR <= 8192, "LDS layout");
+    static_assert(PROW % 4 == 0 && (PLANE / 4) % 8 == 4, "bank layout");
+    static_assert(GEO != 0 || (PROW / 4) % 16 == 8, "bank layout (2 x 16 tiles)");
+    static_assert(GEO != 1 || (PROW / 4) % 4 == 2, "bank layout (4 x 8 tiles)");
+    static_assert(HALO * 4 <= W4_RITEMS * 256, "staging items");
+};
+constexpr int W4_RBUF = 8192;                          // 2 planes + tail, rounded: two buffers = the exchange area
 constexpr int W4_PEX = 4 * 4 * 32 * 32;                // [column j][a][tile][32 channels] floats = 64 KiB
-static_assert(W4_TAIL + (W4_RITEMS * 64 - W4_HALO) * W4_RSTR <= W4_RBUF, "LDS layout");
-static_assert(W4_PROW % 16 == 0 && (W4_PROW / 4) % 4 == 0 && (W4_PLANE / 4) % 8 == 4, "bank layout");
-static_assert(W4_HALO * 4 <= W4_RITEMS * 256, "staging items");
 static_assert(2 * W4_RBUF <= W4_PEX, "LDS layout");
 
 // literal scalar offset only: see conv_wino3.hip (gfx950 b128 buffer-store hazard)
@@ -117,8 +136,11 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
 // content launch's list.  A tile's geometry (H, W, pointers) comes from its segment's descriptor, re-read from the kernel
 // arguments at the two places that need it (the next tile's halo offsets, the epilogue's stores).
 // BIG: per-tile buffer descriptors (any image size); the default form keeps one descriptor per image (tensors below 2 GiB)
-template <int MODE, int DIAG = 0, bool PERSIST = false, bool BIG = false>
+template <int MODE, int DIAG = 0, bool PERSIST = false, bool BIG = false, int GEO = 0>
 __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(ConvArgs a, ConvSegs m, int items, int prio_mode) {
+    using G = W4G<GEO>;
+    constexpr int W4_HALO_W = G::HALO_W, W4_HALO_H = G::HALO_H, W4_HALO = G::HALO, W4_PROW = G::PROW, W4_PLANE = G::PLANE,
+                  W4_TAIL = G::TAIL, TILE_W = G::TILE_W, TILE_H = G::TILE_H, TCL = G::TCOLS_LOG, TCM = (1 << G::TCOLS_LOG) - 1;
     __shared__ __attribute__((aligned(16))) float smem[DIAG == 2 ? W4_PEX + 8192 : (DIAG == 1 ? W4_PEX + 1024 : W4_PEX)];
     float* const Rs = smem;
     unsigned* const steplog = (unsigned*)(smem + W4_PEX);     // DIAG 1, 2: [wave][96] low words of s_memtime
@@ -195,7 +217,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         pt = lid % tiles;
         img = lid / tiles;
     }
-    int tx0 = (pt % gtx) * 32, ty0 = (pt / gtx) * 8;
+    int tx0 = (pt % gtx) * TILE_W, ty0 = (pt / gtx) * TILE_H;
     const int nst = a.cin / W4_KR;
     const int nch = a.cin / 8;
 
@@ -242,7 +264,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 for (int k = 0; k < W4_RITEMS; ++k) {
                     const int idx = t + k * 256;
                     const int hp = min(idx >> 2, W4_HALO - 1), q = idx & 3;
-                    const int hy = (hp * 241) >> 13, hx = hp - hy * W4_HALO_W;          // hp / 34 for hp < 400
+                    const int hy = hp / W4_HALO_W, hx = hp - hy * W4_HALO_W;
                     const int yc = MODE == SRC_UP2X ? (hy + 1) >> 1 : hy, xc = MODE == SRC_UP2X ? (hx + 1) >> 1 : hx;
                     roff[k] = ((yc * Ws + xc) * a.cin + q * 4) * 4;
                 }
@@ -280,7 +302,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
 #pragma unroll
         for (int k = 0; k < W4_RITEMS; ++k) {
             const int hp = (t >> 2) + 64 * k, q = t & 3;
-            const int hy = (hp * 241) >> 13, hx = hp - hy * W4_HALO_W;          // hp / 34 for hp < 400
+            const int hy = hp / W4_HALO_W, hx = hp - hy * W4_HALO_W;
             sa[k] = hp < W4_HALO ? (hx & 1) * W4_PLANE + hy * W4_PROW + (hx >> 1) * W4_RSTR + q * 4
                                  : W4_TAIL + (hp - W4_HALO) * W4_RSTR + q * 4;
             asm volatile("" : "+v"(sa[k]));      // held in a register: left alone the compiler recomputes it (8 vector
@@ -351,8 +373,8 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
             const int orow0 = a.pool_out ? ty0 >> 1 : ty0;
             dst = make_rsrc(eout + ((size_t)img * Ho + orow0) * Wo * a.cout, 0x7ffffff0u);      // stores are masked per lane, never range-checked
         }
-        const int oy = ty0 + 4 * (tl >> 4), ox = tx0 + 2 * (tl & 15);
-        const int ry = BIG ? 4 * (tl >> 4) : oy;                           // row counted from the descriptor's origin
+        const int oy = ty0 + 4 * (tl >> TCL), ox = tx0 + 2 * (tl & TCM);
+        const int ry = BIG ? 4 * (tl >> TCL) : oy;                         // row counted from the descriptor's origin
         const int cbyte = (ct * 32 + 4 * q8) * 4;
         const bool colok0 = ox < eW, colok1 = ox + 1 < eW;
         const float relu_lo = a.relu ? 0.f : -__builtin_inff();
@@ -437,12 +459,12 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         int xaddr = 0;          // this lane's patch origin in the halo image (floats): computed once, held in a register
         {
             const int li = lane & 31, lh = lane >> 5;
-            xaddr = (4 * (li >> 4)) * W4_PROW + (li & 15) * W4_RSTR + 4 * lh;
+            xaddr = (4 * (li >> TCL)) * W4_PROW + (li & TCM) * W4_RSTR + 4 * lh;
             asm volatile("" : "+v"(xaddr));
         }
         auto xf_addr = [&]() {};
         // patch pixel (row a, column c of the 6 x 4 patch) relative to xaddr: plane c & 1, plane column + (c >> 1)
-        auto poff = [](int a, int c) { return (c & 1) * W4_PLANE + a * W4_PROW + (c >> 1) * W4_RSTR; };
+        auto poff = [=](int a, int c) { return (c & 1) * W4_PLANE + a * W4_PROW + (c >> 1) * W4_RSTR; };
         auto xf_read3 = [&](const float* rb, int a0) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -608,7 +630,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 const int nli = nitem - m.s[nseg].item0, ngtx = m.s[nseg].tiles_x, ntiles = ngtx * m.s[nseg].tiles_y;
                 int nct_, npt, nimg;
                 decode(nli, ntiles, m.s[nseg].n, nct_, npt, nimg);
-                const int ntx0 = (npt % ngtx) * 32, nty0 = (npt / ngtx) * 8;
+                const int ntx0 = (npt % ngtx) * TILE_W, nty0 = (npt / ngtx) * TILE_H;
                 const int wso_next = ((nct_ * 4 + wj) * nch) * 6144;
                 if (prio_mode & 1) {
                     if ((ntile + (int)((blockIdx.x >> 3) >= (stride >> 1))) & 1) __builtin_amdgcn_s_setprio(1);
@@ -705,10 +727,11 @@ static int check_wino4_shape(const ConvArgs& a, int src_mode) {
     if (a.cin % W4_KR || a.cin < W4_KR) { set_error("conv3x3_wino4: cin %d not a multiple of 16", a.cin); return -1; }
     if (a.cout % 32) { set_error("conv3x3_wino4: cout %d not a multiple of 32", a.cout); return -1; }
     if (a.H < 2 || a.W < 2 || a.n < 1) { set_error("conv3x3_wino4: H, W must be >= 2, got %dx%d", a.H, a.W); return -1; }
-    // 32-bit offsets address a band of 10 source / 8 output rows from a per-tile descriptor: the image itself may be of any size
-    if ((size_t)a.Ws * a.cin * 4 * 10 >= 0x7ffffff0ULL || (size_t)a.W * a.cout * 4 * 8 >= 0x7ffffff0ULL) {
-        set_error("conv3x3_wino4: a band of ten %d-channel source rows or eight %d-channel output rows of width %d reaches 2 GiB", a.cin,
-                  a.cout, a.W);
+    // 32-bit offsets address a band of at most 18 source / 16 output rows (the taller tile geometry) from a per-tile descriptor: the
+    // image itself may be of any size
+    if ((size_t)a.Ws * a.cin * 4 * 18 >= 0x7ffffff0ULL || (size_t)a.W * a.cout * 4 * 16 >= 0x7ffffff0ULL) {
+        set_error("conv3x3_wino4: a band of eighteen %d-channel source rows or sixteen %d-channel output rows of width %d reaches 2 GiB",
+                  a.cin, a.cout, a.W);
         return -1;
     }
     if ((size_t)a.cin * a.cout * 96 >= 0xffffffffULL) { set_error("conv3x3_wino4: packed weights must stay below 4 GiB"); return -1; }
@@ -746,11 +769,51 @@ static long long persistent_grid() {
     return pgrid - pgrid % 8;
 }
 
+// Tile geometry of a launch: 0 = 8 x 32 output pixels per workgroup tile (the tuned default), 1 = 16 x 16.  Both cost the same per
+// tile, so the one that covers the launch's feature maps with fewer tiles wins; the default keeps ties and near-ties (1 %).
+static int tile_h(int geo) { return geo ? 16 : 8; }
+static int tile_w(int geo) { return geo ? 16 : 32; }
+static long long geo_tiles(int geo, int n, int H, int W) {
+    return (long long)n * ((H + tile_h(geo) - 1) / tile_h(geo)) * ((W + tile_w(geo) - 1) / tile_w(geo));
+}
+static int pick_geo(const ConvSeg* segs, int count) {
+    static const int force = tune_env("ADAIN_W4_GEO", -1);      // diagnostic build: -1 = automatic, 0 / 1 = that geometry
+    if (force == 0 || force == 1) return force;
+    long long t0 = 0, t1 = 0;
+    for (int i = 0; i < count; ++i) {
+        t0 += geo_tiles(0, segs[i].n, segs[i].H, segs[i].W);
+        t1 += geo_tiles(1, segs[i].n, segs[i].H, segs[i].W);
+    }
+    return t1 * 101 < t0 * 100 ? 1 : 0;
+}
+
+template <int MODE, bool PERSIST, bool BIG>
+static void w4_launch_geo(int geo, dim3 grid, hipStream_t s, const ConvArgs& a, const ConvSegs& m, int items, int prio) {
+    if (geo) hipLaunchKernelGGL((conv3x3_wino4_kernel<MODE, 0, PERSIST, BIG, 1>), grid, dim3(256), 0, s, a, m, items, prio);
+    else hipLaunchKernelGGL((conv3x3_wino4_kernel<MODE, 0, PERSIST, BIG, 0>), grid, dim3(256), 0, s, a, m, items, prio);
+}
+static void w4_launch(int src_mode, bool persist, bool big, int geo, dim3 grid, hipStream_t s, const ConvArgs& a, const ConvSegs& m,
+                      int items, int prio) {
+    const bool up = src_mode == SRC_UP2X;
+    if (persist) {
+        if (big) up ? w4_launch_geo<SRC_UP2X, true, true>(geo, grid, s, a, m, items, prio) : w4_launch_geo<SRC_DIRECT, true, true>(geo, grid, s, a, m, items, prio);
+        else up ? w4_launch_geo<SRC_UP2X, true, false>(geo, grid, s, a, m, items, prio) : w4_launch_geo<SRC_DIRECT, true, false>(geo, grid, s, a, m, items, prio);
+    } else {
+        if (big) up ? w4_launch_geo<SRC_UP2X, false, true>(geo, grid, s, a, m, items, prio) : w4_launch_geo<SRC_DIRECT, false, true>(geo, grid, s, a, m, items, prio);
+        else up ? w4_launch_geo<SRC_UP2X, false, false>(geo, grid, s, a, m, items, prio) : w4_launch_geo<SRC_DIRECT, false, false>(geo, grid, s, a, m, items, prio);
+    }
+}
+
 int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     ConvArgs a = a0;
     if (check_wino4_shape(a, src_mode)) return -1;
-    a.tiles_x = (a.W + 31) / 32;
-    a.tiles_y = (a.H + 7) / 8;
+    ConvSegs m{};
+    m.count = 1;
+    m.s[0] = ConvSeg{a.in, a.out, a.n, a.H, a.W, a.Hs, a.Ws, 0, 0, 0};
+    const int geo = a.dbg ? 0 : pick_geo(m.s, 1);               // the stamp / timing-only builds exist for the default geometry
+    a.tiles_x = (a.W + tile_w(geo) - 1) / tile_w(geo);
+    a.tiles_y = (a.H + tile_h(geo) - 1) / tile_h(geo);
+    m.s[0].tiles_x = a.tiles_x; m.s[0].tiles_y = a.tiles_y;
     const long long blocks = (long long)a.tiles_x * a.tiles_y * (a.cout / 32) * a.n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv3x3_wino4: bad grid %lld", blocks); return -1; }
     static const int order_env = tune_env("ADAIN_W4_ORDER", 1);
@@ -766,17 +829,10 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     const bool persist = !a.dbg && persist_ok;
     const int items = (int)blocks;
     const bool big = wino4_big(a);
-    ConvSegs m{};
-    m.count = 1;
     m.ctg = walk_group(a.cin, a.cout);
     m.stagger = tune_env("ADAIN_W4_STAGGER", W4_STAGGER);
-    m.s[0] = ConvSeg{a.in, a.out, a.n, a.H, a.W, a.Hs, a.Ws, a.tiles_x, a.tiles_y, 0};
     if (persist) {
-        const dim3 pg((unsigned)pgrid);
-        if (big && src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true, true>), pg, dim3(256), 0, s, a, m, items, prio_env);
-        else if (big) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, true, true>), pg, dim3(256), 0, s, a, m, items, prio_env);
-        else if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true>), pg, dim3(256), 0, s, a, m, items, prio_env);
-        else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, true>), pg, dim3(256), 0, s, a, m, items, prio_env);
+        w4_launch(src_mode, true, big, geo, dim3((unsigned)pgrid), s, a, m, items, prio_env);
         return check_launch("conv3x3_wino4");
     }
 #ifdef ADAIN_DIAG
@@ -798,10 +854,7 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
         return check_launch("conv3x3_wino4(diag)");
     }
 #endif
-    if (big && src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, false, true>), g, dim3(256), 0, s, a, m, items, 0);
-    else if (big) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, false, true>), g, dim3(256), 0, s, a, m, items, 0);
-    else if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X>), g, dim3(256), 0, s, a, m, items, 0);
-    else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT>), g, dim3(256), 0, s, a, m, items, 0);
+    w4_launch(src_mode, false, big, geo, g, s, a, m, items, 0);
     return check_launch("conv3x3_wino4");
 }
 
@@ -814,6 +867,7 @@ int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int c
     long long total = 0;
     bool big = false;
     ConvArgs a = layer;
+    const int geo = pick_geo(segs, count);                       // one geometry per launch: the one with fewer tiles over all segments
     for (int i = 0; i < count; ++i) {
         a.in = segs[i].in; a.out = segs[i].out; a.n = segs[i].n;
         a.H = segs[i].H; a.W = segs[i].W; a.Hs = segs[i].Hs; a.Ws = segs[i].Ws;
@@ -821,8 +875,8 @@ int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int c
         if (check_wino4_shape(a, src_mode)) return -1;
         big = big || wino4_big(a);
         m.s[i] = segs[i];
-        m.s[i].tiles_x = (a.W + 31) / 32;
-        m.s[i].tiles_y = (a.H + 7) / 8;
+        m.s[i].tiles_x = (a.W + tile_w(geo) - 1) / tile_w(geo);
+        m.s[i].tiles_y = (a.H + tile_h(geo) - 1) / tile_h(geo);
         m.s[i].item0 = (int)total;
         total += (long long)m.s[i].tiles_x * m.s[i].tiles_y * (a.cout / 32) * a.n;
         if (total > 0x7fffffffLL) { set_error("conv3x3_wino4_multi: too many tiles"); return -1; }
@@ -845,11 +899,7 @@ int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int c
     a.tiles_x = m.s[0].tiles_x; a.tiles_y = m.s[0].tiles_y;
     a.xcd_order = 1;
     a.dbg = nullptr;
-    const dim3 pg((unsigned)pgrid);
-    if (big && src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true, true>), pg, dim3(256), 0, s, a, m, (int)total, prio_env);
-    else if (big) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, true, true>), pg, dim3(256), 0, s, a, m, (int)total, prio_env);
-    else if (src_mode == SRC_UP2X) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, 0, true>), pg, dim3(256), 0, s, a, m, (int)total, prio_env);
-    else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, 0, true>), pg, dim3(256), 0, s, a, m, (int)total, prio_env);
+    w4_launch(src_mode, true, big, geo, dim3((unsigned)pgrid), s, a, m, (int)total, prio_env);
     return check_launch("conv3x3_wino4(multi)");
 }
 

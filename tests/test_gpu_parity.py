@@ -198,7 +198,34 @@ def test_conv3x3_winograd_f43_full_grids(rt, mode, shape):
           F.max_pool2d(F.relu(pre), 2, 2, 0, ceil_mode=True))
 
 
-@pytest.mark.parametrize("mode,shape", [("direct", (2, 32, 64, 256, 250)), ("direct", (1, 64, 128, 300, 260)), ("up", (1, 64, 64, 200, 180)),
+@pytest.mark.parametrize("mode,shape", [("direct", (1, 64, 128, 300, 400)), ("direct", (4, 32, 64, 150, 200)), ("direct", (1, 128, 256, 150, 200)),
+                                        ("up", (1, 64, 64, 75, 100)), ("direct", (3, 48, 64, 150, 200)), ("direct", (2, 64, 32, 16, 16)),
+                                        ("up", (2, 64, 128, 150, 200)), ("direct", (1, 64, 64, 57, 112))])
+def test_conv3x3_winograd_f43_16x16_tile_geometry(rt, mode, shape):
+    """Shapes whose feature maps the 16 x 16 tile geometry covers with fewer tiles than the default 8 x 32 (W = 400 / 200 / 114 ...):
+    the launcher then runs the second layout of the kernel (4 x 8 Winograd tiles, 18 x 18 halo) - persistent and one-tile
+    launches, two- / three- / many-stage K loops, batches, up-sampled source, ragged edges, fused pool, determinism."""
+    import applied_image_processing_amd.arch as arch
+
+    n, cin, cout, hs, ws = shape
+    h, w = (2 * hs, 2 * ws) if mode == "up" else (hs, ws)
+    assert arch.wino4_geometry([(n, h, w)]) == 1
+    x = T(synth.uniform_sym(440 + cin, (n, cin, hs, ws), 1.0))
+    wt = T(synth.uniform_sym(540 + cout, (cout, cin, 3, 3), (6.0 / (9 * cin)) ** 0.5))
+    b = T(synth.uniform_sym(640 + cout, (cout,), 0.1))
+    src = F.interpolate(x, scale_factor=2, mode="nearest") if mode == "up" else x
+    pre = F.conv2d(F.pad(src, (1, 1, 1, 1), mode="reflect"), wt, b)
+    xg = x.cuda().permute(0, 2, 3, 1).contiguous()
+    packed = rt.conv3x3_wino_pack(wt.cuda(), 5)
+    m = rt.SRC_UP2X if mode == "up" else rt.SRC_DIRECT
+    out = rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=False, m_tiles=5)
+    close(out.permute(0, 3, 1, 2), pre)
+    assert torch.equal(out, rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=False, m_tiles=5))      # deterministic
+    close(rt.conv3x3_wino(xg, packed, b.cuda(), cout, m, relu=True, pool_out=True, m_tiles=5).permute(0, 3, 1, 2),
+          F.max_pool2d(F.relu(pre), 2, 2, 0, ceil_mode=True))
+
+
+@pytest.mark.parametrize("mode,shape", [("direct", (2, 32, 64, 256, 250)), ("direct", (1, 64, 128, 296, 250)), ("up", (1, 64, 64, 200, 176)),
                                         ("direct", (3, 48, 64, 203, 340))])
 def test_conv3x3_winograd_f43_persistent_tile_lists(rt, mode, shape):
     """Launches with at least two tiles per resident workgroup take the persistent form of the F(4,3) x F(2,3) kernel: tile
@@ -206,6 +233,9 @@ def test_conv3x3_winograd_f43_persistent_tile_lists(rt, mode, shape):
     (cin = 32), three-stage (cin = 48), several images, ragged edges, fused pool."""
     n, cin, cout, hs, ws = shape
     h, w = (2 * hs, 2 * ws) if mode == "up" else (hs, ws)
+    import applied_image_processing_amd.arch as arch
+
+    assert arch.wino4_geometry([(n, h, w)]) == 0                                   # the default 8 x 32 geometry
     assert ((w + 31) // 32) * ((h + 7) // 8) * (cout // 32) * n >= 1024          # the launcher's persistence threshold on 256 CUs
     x = T(synth.uniform_sym(430 + cin, (n, cin, hs, ws), 1.0))
     wt = T(synth.uniform_sym(530 + cout, (cout, cin, 3, 3), (6.0 / (9 * cin)) ** 0.5))
