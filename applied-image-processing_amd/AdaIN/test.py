@@ -307,8 +307,11 @@ def composite_with_mask(content, output_img, content_mask):
         mask_tensor = torch.from_numpy(np.ascontiguousarray(content_mask)).float().to(content.device)
     mask_tensor = mask_tensor.unsqueeze(0)
     size = tuple(content.shape[-2:])
-    mask_tensor = rt.resize_nearest(mask_tensor, size)
-    output_img = rt.resize_bilinear(output_img, size)
+    # interpolating to the size a tensor already has is the identity in both modes: skipped (see engine.AdaINEngine.composite)
+    if tuple(mask_tensor.shape[-2:]) != size:
+        mask_tensor = rt.resize_nearest(mask_tensor.contiguous(), size)
+    if tuple(output_img.shape[-2:]) != size:
+        output_img = rt.resize_bilinear(output_img, size)
     if content.shape[1] != output_img.shape[1]:
         raise ValueError(f"content has {content.shape[1]} channels but the stylised output has {output_img.shape[1]}")
     return rt.mask_composite(content.contiguous(), output_img, mask_tensor)

@@ -95,9 +95,14 @@ class AdaINEngine:
         content = content.to(self.device)
         content = rt.u8_to_f32(content.contiguous()) if content.dtype == torch.uint8 else content.to(torch.float32).contiguous()
         size = tuple(content.shape[-2:])
-        m = rt.resize_nearest(masks.to(self.device, torch.float32), size)
-        s = rt.resize_bilinear(stylized, size)
-        return rt.mask_composite(content, s, m)
+        # F.interpolate to the size a tensor already has is the identity for both modes (nearest: index i -> i; bilinear with
+        # align_corners=False: source coordinate i exactly, weight 0 on the neighbour), so equal sizes skip the two resize passes
+        # (24 B per pixel each): the usual case - frames whose sides are multiples of 8, masks made from the frame itself
+        m = masks.to(self.device, torch.float32).contiguous()
+        if tuple(m.shape[-2:]) != size:
+            m = rt.resize_nearest(m, size)
+        s = stylized if tuple(stylized.shape[-2:]) == size else rt.resize_bilinear(stylized, size)
+        return rt.mask_composite(content, s.contiguous(), m)
 
     def to_u8(self, images, out=None):
         return rt.quantize_u8(images, out)

@@ -95,17 +95,21 @@ class _Batch:
 class FrameFeeder:
     """Feeds ``frames[lo:hi]`` to the compute loop as sub-batches that are already on the device.
 
-    A worker thread fetches the frames (``frames[k]`` may decode a file), cuts sub-batches (at most ``sub_batch`` frames of
-    one style, one size and one kind), copies them into a pinned staging slot and uploads the slot on a dedicated copy stream;
-    the per-frame proximity maps and masks of the sub-batch ride along.  ``depth`` slots are in flight: the upload of sub-batch
-    k+1 (and the decode of k+2) overlaps the kernels of sub-batch k.  The consumer waits on the sub-batch's HIP event on ITS
-    stream (no host synchronisation) and calls ``release`` once its last kernel reading the slot is enqueued.
+    A feeder thread cuts sub-batches (at most ``sub_batch`` frames of one style, one size and one kind), copies them into a
+    pinned staging slot and uploads the slot on a dedicated copy stream; the per-frame proximity maps and masks of the sub-batch
+    ride along.  The frames themselves are fetched (``frames[k]`` may decode a file: it must be safe to call for different k
+    from several threads) and copied into the pinned slot by a small pool of ``workers`` threads, a window of frames ahead of
+    the cutter: PIL's decoders and numpy's memcpy release the interpreter lock, and ONE thread copying pageable frames into
+    pinned memory was measured at 0.7-1.1 GB/s on the GPU box - a 1080p job needs 1 GB/s.  ``depth`` slots are in flight: the
+    upload of sub-batch k+1 (and the decode of k+2 ...) overlaps the kernels of sub-batch k.  The consumer waits on the
+    sub-batch's HIP event on ITS stream (no host synchronisation) and calls ``release`` once its last kernel reading the slot
+    is enqueued.
 
     ``frames`` may offer ``block(i, j)`` -> a ready [j-i, ...] tensor of frames i..j-1 of one size (device-resident frame
     stores hand out views: no staging, no copy).  On a CPU engine (tests) the same thread and cutting logic run without
     pinned memory or streams."""
 
-    def __init__(self, frames, lo, hi, style_of, sub_batch, device, depth_maps=None, masks=None, depth=3, cuts=()):
+    def __init__(self, frames, lo, hi, style_of, sub_batch, device, depth_maps=None, masks=None, depth=4, cuts=(), workers=4):
         self.frames, self.lo, self.hi, self.style_of, self.sub_batch = frames, lo, hi, style_of, max(1, int(sub_batch))
         self.cuts = set(cuts)              # frame indices at which a sub-batch must end (chunk borders of a chunked gather)
         self.device = torch.device(device)
@@ -126,6 +130,8 @@ class FrameFeeder:
             self.pinned, self.dev = {}, {}         # (slot, "content" | "mask" | "depth") -> staging buffers
             self.h2d_done = [None] * self.nslots
             self.consumed = [None] * self.nslots
+        self.pool = ThreadPoolExecutor(max_workers=max(1, int(workers)), thread_name_prefix="adain-frame-fetch")
+        self.window = max(2 * self.sub_batch, 2 * max(1, int(workers)))      # frames fetched ahead of the cutter
         self.thread = threading.Thread(target=self._run, name="adain-frame-feeder", daemon=True)
         self.thread.start()
 
@@ -134,6 +140,18 @@ class FrameFeeder:
         """Yields (i, j, frames-or-block, kind) for consecutive sub-batches of [lo, hi)."""
         k, carry = self.lo, None
         block = getattr(self.frames, "block", None)
+        ahead, nxt = [], self.lo               # futures of frames nxt - len(ahead) .. nxt - 1, fetched by the pool in index order
+
+        def fetch(idx):
+            return as_frame(self.frames[idx])
+
+        def get(idx):
+            nonlocal nxt
+            while nxt < self.hi and len(ahead) < self.window and not self.stop.is_set():
+                ahead.append(self.pool.submit(fetch, nxt))
+                nxt += 1
+            return ahead.pop(0).result()
+
         while k < self.hi:
             i = k
             if block is not None:
@@ -146,7 +164,7 @@ class FrameFeeder:
                 continue
             items, kind = [], None
             while k < self.hi and len(items) < self.sub_batch and self.style_of[k] == self.style_of[i] and not (items and k in self.cuts):
-                fr, kd = carry if carry is not None else as_frame(self.frames[k])
+                fr, kd = carry if carry is not None else get(k)
                 carry = None
                 if items and (kd != kind or fr.shape != items[0].shape or fr.device != items[0].device):
                     carry = (fr, kd)          # another size / kind: it opens the next sub-batch
@@ -175,8 +193,15 @@ class FrameFeeder:
         if pin is None or pin.shape != shape or pin.dtype != items[0].dtype:
             pin = self.pinned[key] = torch.empty(shape, dtype=items[0].dtype, pin_memory=True)
             self.dev[key] = torch.empty(shape, dtype=items[0].dtype, device=self.device)
-        for q_, it in enumerate(items):
-            pin[q_].copy_(it)
+        pin_np = pin.numpy()
+
+        def put(q_, it):
+            np.copyto(pin_np[q_], it.numpy())              # a plain memcpy outside the interpreter lock
+
+        if nb > 1:
+            list(self.pool.map(put, range(nb), items))
+        else:
+            put(0, items[0])
         self.dev[key][:nb].copy_(pin[:nb], non_blocking=True)
         self.h2d_bytes += nb * items[0].numel() * items[0].element_size()
         return self.dev[key][:nb]
@@ -291,6 +316,7 @@ class FrameFeeder:
         for _ in range(self.nslots + 1):
             self.free.release()
         self.thread.join(30)
+        self.pool.shutdown(wait=True, cancel_futures=True)
 
 
 class HostCopier:
@@ -395,7 +421,7 @@ def _elapsed(engine, a, b):
 def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, depth_maps=None, depth_offset=0.15,
                            depth_prominence=20, masks=None, post=None, sub_batch=4, group=None, dst=0, gather=True,
                            require_transport=None, style_cache=None, out_hw=None, gather_chunks=1, agree=True, sink=None,
-                           prefetch=3, host_out=None):
+                           prefetch=4, host_out=None, fetch_workers=4):
     """Stylises ``frames`` (a sequence indexed lazily: a rank only ever touches its own block; an element is a decoded
     frame uint8 [h,w,3] / RGB PIL image, or a float tensor [3,h,w] in [0,1]) and returns ``(frames_u8, info)``: the uint8
     frames [n,H,W,3] in frame order on rank ``dst`` (None on the other ranks; with ``gather=False`` the local block — a
@@ -455,7 +481,7 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
     err = None
     copier = HostCopier(dev) if host_out is not None else None
     feeder = FrameFeeder(frames, lo, hi, style_of, sub_batch, dev, depth_maps, masks, depth=prefetch,
-                         cuts=[lo + b for (_, b) in my_chunks] if chunks > 1 else ())
+                         cuts=[lo + b for (_, b) in my_chunks] if chunks > 1 else (), workers=fetch_workers)
 
     def chunk_ready(c, done_upto):
         return lo + my_chunks[c][1] <= done_upto

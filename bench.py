@@ -9,12 +9,13 @@ A "step" is one pass of the hot path over one batch of synthetic frames that are
             1024x1024 content, encode the 512x512 style (re-encoded every step, as every reference call does), statistics,
             AdaIN + alpha blend, decode.
   config 3  the depth-aware ``style_transfer`` (test.py:52-71) at 2048x2048 with a proximity map.
-  config 4  the video job (video/utils.py:297-369): ``--batch`` 1080p frames per GPU per step through
-            ``jobs.stylize_frames_sharded`` (one style for the clip: its statistics are computed once per rank), uint8 out.
-  config 5  the 3DGS guide-view job (Style_3DGS/train.py:86-115): ``--batch`` masked 1200x1600 views per GPU per step.
+  config 4  one sub-batch of the video job (video/utils.py:297-369): ``--batch`` 1080p frames per GPU per step (one style for the
+            clip: its statistics are computed once per rank), uint8 out.  ``--job`` runs the whole 512-frame job (below).
+  config 5  one sub-batch of the 3DGS guide-view job (Style_3DGS/train.py:86-115): ``--batch`` masked 1200x1600 views per GPU per
+            step, mask composite + uint8 out.  ``--job`` runs the whole 300-view job.
 With more than one rank (or under torch.distributed.run) the frame list of a step is cut into contiguous per-rank blocks
 (weak scaling: ``--batch`` frames per GPU) and every step ENDS with the path's one collective: the finished uint8 frames are
-gathered to rank 0 over RCCL (asynchronously for configs 2/3: the gather of step k overlaps the compute of step k+1).  The
+gathered to rank 0 over RCCL (asynchronously: the gather of step k overlaps the compute of step k+1).  The
 device gather must run over RCCL ("nccl" backend): if the process group cannot provide it, or if there are more ranks than
 GPUs, the benchmark exits non-zero instead of silently degrading (``--rehearse`` allows both for single-GPU rehearsals and
 labels the JSON line).  The timed region is bracketed by barrier + synchronize; the MAX over ranks is reported.
@@ -82,8 +83,8 @@ CONV_KERNEL = ("conv3x3_mfma_kernel / conv3x3_persist_kernel" if not WINOGRAD el
 WORKLOADS = {
     2: "configs[1]: {h}x{w} AdaIN forward (style_transfer_simple), batch={b} per GPU, style {hs}x{ws} re-encoded every step, alpha=0.5",
     3: "configs[2]: {h}x{w} depth-aware AdaIN (style_transfer, proximity-map blend), batch={b} per GPU, style {hs}x{ws} re-encoded every step",
-    4: "configs[3]: video job, frames {h}x{w}, {b} frames per GPU per step, one {hs}x{ws} style (statistics cached per rank), uint8 out",
-    5: "configs[4]: 3DGS guide-view job, views {h}x{w} with masks, {b} views per GPU per step, one {hs}x{ws} style, mask composite + uint8 out",
+    4: "configs[3]: one sub-batch of the video job per step, frames {h}x{w}, {b} frames per GPU per step, one {hs}x{ws} style (statistics cached per rank), uint8 out",
+    5: "configs[4]: one sub-batch of the 3DGS guide-view job per step, views {h}x{w} with masks, {b} views per GPU per step, one {hs}x{ws} style, mask composite + uint8 out",
 }
 SIZES = {2: (1024, 1024), 3: (2048, 2048), 4: (1080, 1920), 5: (1200, 1600)}
 
@@ -226,40 +227,6 @@ class Step:
             self.style_cache = {0: (self.s_mean, self.s_std)}      # one style for the whole job: encoded once per rank
         self.spans = []
 
-    def job_inputs(self, n_job):
-        """The step's job as the job driver sees it: a frame list of ``n_job`` entries (and masks for config 5) of which only
-        this rank's block exists - it is resident in HBM; touching a foreign frame is an error."""
-        step = self
-
-        class Block:
-            def __init__(self, t):
-                self.t = t
-
-            def __len__(self):
-                return n_job
-
-            def __getitem__(self, k):
-                i = k - step.first_frame
-                if not 0 <= i < step.batch:
-                    raise IndexError(f"frame {k} belongs to another rank")
-                return self.t[i]
-
-            def block(self, i, j):                      # resident frames: the job driver takes views, no staging
-                if not (step.first_frame <= i < j <= step.first_frame + step.batch):
-                    raise IndexError(f"frames {i}..{j - 1} belong to another rank")
-                return self.t[i - step.first_frame:j - step.first_frame]
-
-        return Block(self.content), (Block(self.mask) if self.config == 5 else None)
-
-    def run_job(self, n_job, gather, require_transport=None):
-        """Configs 4 / 5: one step = the sharded job driver over this step's frame list (stylise the own block, [mask
-        composite,] uint8, one gather to rank 0)."""
-        frames, masks = self.job_inputs(n_job)
-        res, info = jobs.stylize_frames_sharded(self.engine, frames, self.style, alpha=self.alpha, masks=masks, sub_batch=self.batch,
-                                                gather=gather, require_transport=require_transport, style_cache=self.style_cache,
-                                                out_hw=(self.h, self.w), agree=False)       # per-step mode: no status word per step
-        return res, info
-
     def flops_per_step(self):
         f = arch.conv_flops_encoder(self.h, self.w) * self.batch + arch.conv_flops_decoder(self.hc, self.wc) * self.batch
         if self.style_each_step:
@@ -333,10 +300,9 @@ class Step:
             ev += [(ev_d[i], ev_d[i + 1]) for i in range(8)]
             self.edge_ev.append(("conv_last_kernel (64-ch NHWC -> NCHW image)", px * (256 + 12), ev_d[8], ev_d[9]))
         if self.config == 5:
-            size = (self.h, self.w)
-            rs = T("resize_bilinear_kernel", 2 * px * 12, rt.resize_bilinear, out, size)
-            mk = T("resize_nearest_kernel", 2 * px * 12, rt.resize_nearest, self.mask, size)
-            out = T("mask_composite_kernel", 4 * px * 12, rt.mask_composite, self.content, rs, mk)
+            # the decoder's output and the mask already have the view's size (1200 x 1600: multiples of 8; mask = view > 0): the two
+            # F.interpolate calls of test.py:222-236 are identities and the engine skips them (engine.AdaINEngine.composite)
+            out = T("mask_composite_kernel", 4 * px * 12, rt.mask_composite, self.content, out, self.mask)
         if self.config in (4, 5) or to_u8:
             self.u8 = T("quantize_u8_kernel", px * 15, rt.quantize_u8, out)
         self.spans = T.spans
@@ -709,22 +675,10 @@ def main():
 
     pending = []
     gathered = [None]
-    job_mode = args.config in (4, 5)
-    job_info = {}
 
     def one_step():
-        if job_mode:          # the job driver on one sub-batch per rank and step: shard -> stylise -> [composite] -> uint8 -> gather
-            via_rccl = use_dist and transport == "rccl"
-            res, info = step.run_job(n_job, gather=via_rccl, require_transport="rccl" if via_rccl and world > 1 else None)
-            job_info.update(info)
-            if use_dist and not via_rccl:             # rehearsal: host copies over gloo
-                step.u8 = res
-                gathered[0] = sh.gather_frames(res.cpu(), n_job, dst=0)
-            else:
-                gathered[0] = res
-                if rank == 0 or not use_dist:
-                    step.u8 = res[:args.batch]
-            return None
+        # every config: the C-ABI call sequence of one forward on the step's resident frames (configs 4 / 5 end with their uint8
+        # quantiser / mask composite); whole jobs through the sharded driver are `--job`
         out = step.run(to_u8=use_dist)
         if use_dist:                                  # the path's one collective: finished uint8 frames -> rank 0
             u8 = step.u8 if transport == "rccl" else step.u8.cpu()
@@ -758,8 +712,6 @@ def main():
     # one isolated gather (nothing else in flight) for the transport's own cost
     gather_ms = None
     if use_dist:
-        if job_mode and rank != 0:
-            step.run(to_u8=True)                      # ranks other than 0 hold no local block after a gathered job
         u8 = step.u8 if transport == "rccl" else step.u8.cpu()
         barrier()
         g0 = time.perf_counter()
@@ -779,9 +731,7 @@ def main():
         result["step_tflops"] = round(step.flops_per_step() / (dt / args.steps) / 1e12 * world, 2)
         if use_dist:
             result["gather"] = {"in_timed_step": True, "transport": transport, "isolated_ms": round(gather_ms, 3),
-                                "bytes_per_rank": int(step.u8.numel()), "overlapped_with_next_step": not job_mode}
-            if job_mode:
-                result["gather"]["last_job_gather_ms"] = round(job_info.get("gather_s", 0.0) * 1e3, 3)
+                                "bytes_per_rank": int(step.u8.numel()), "overlapped_with_next_step": True}
             if args.rehearse:
                 result["rehearsal"] = {"ranks_share_a_gpu": shared_gpu, "note": "not a multi-GPU measurement"}
         if args.pcie:
@@ -800,8 +750,6 @@ def main():
                                         "ms_per_step": round(pdt * 1e3, 4), "what": "pinned fp32 frame H2D + forward + uint8 D2H per step"}
         if world == 1 and not args.no_secondary:
             result["secondary"] += measure_pixel_kernels(device)
-        if job_mode:
-            result["job_driver"] = "jobs.stylize_frames_sharded (one sub-batch per step; --job runs the whole BASELINE job)"
         if world == 1 and not args.no_cpu:
             out = step.run()
             torch.cuda.synchronize()
