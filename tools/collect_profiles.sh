@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of profiles/ on the GPU box (kernel traces and SEPARATE --pmc passes; never combined with
 # sys/hip/hsa tracing; the program goes straight after `--`).
-# Usage: tools/collect_profiles.sh <tag> [part ...]    parts: trace pmc configs all_kernels  (default: all four)
+# Usage: tools/collect_profiles.sh <tag> [part ...]    parts: trace pmc configs waits all_kernels  (default: all but waits)
 #   -> gpurun_out/prof_<tag>_{trace,fetch,write,sq,cfg3_trace,cfg4_trace,cfg5_trace,all_kernels}
 set -o pipefail
 tag="$1"; shift; parts="${*:-trace pmc configs all_kernels}"
@@ -26,6 +26,11 @@ for part in $parts; do
     configs)
       for cfg in 3 4 5; do
         BENCH_ARGS="--config $cfg --no-cpu --no-secondary --steps 5 --warmup 1" run cfg${cfg}_trace 300 bench.py --kernel-trace --stats
+      done ;;
+    waits)   # wave-state and L2 hit/miss counters of configs 2 and 3 (is the larger map's extra L2-miss traffic free?)
+      for cfg in 2 3; do
+        BENCH_ARGS="--config $cfg --no-cpu --no-secondary --steps 3 --warmup 1" run cfg${cfg}_waits 300 bench.py --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace
+        BENCH_ARGS="--config $cfg --no-cpu --no-secondary --steps 3 --warmup 1" run cfg${cfg}_tcc 300 bench.py --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace
       done ;;
     all_kernels)
       BENCH_ARGS="" run all_kernels 300 tools/all_kernels.py --kernel-trace --stats ;;

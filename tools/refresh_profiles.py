@@ -1,120 +1,161 @@
 #!/usr/bin/env python3
-"""Turns one collection run (tools/gpu_steps.sh bench lines `<tag>_c*.log` + tools/collect_profiles.sh `prof_<tag>_*`, merged
-back under gpurun_out/) into the committed evidence under profiles/: r02_bench_*.json, r02_kernel_trace.md, r02_kernel_stats.csv,
-r02_pmc.md (the appended probe sections are kept), pmc_traffic.json.   python tools/refresh_profiles.py <tag>"""
+"""Turns one collection run merged back under gpurun_out/ into the committed evidence under profiles/ for a round:
+
+    python tools/refresh_profiles.py <round, e.g. r03> <bench tag> <profile tag>
+
+bench lines   gpurun_out/<bench tag>_{c2,c2_pcie,c3,c4,c5,c4job,c5job,c2_ws1,c4job_ws1,c5job_ws1}.log   (tools/gpu_steps.sh)
+profiles      gpurun_out/prof_<profile tag>_*                                             (tools/collect_profiles.sh, collect_traffic.sh)
+-> profiles/<round>_bench_*.json, <round>_kernel_trace*.md, <round>_kernel_stats.csv, <round>_all_kernels.md, <round>_pmc.md,
+   <round>_gaps.md, pmc_traffic.json.  Every file's header names the commit it was taken at (HEAD when this script runs: run it
+   before changing the code again)."""
 import csv
 import glob
 import io
 import json
 import os
+import re
 import shutil
 import subprocess
 import sys
+from collections import defaultdict
 from contextlib import redirect_stdout
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gap_report  # noqa: E402
 import summarize_rocprof as sr  # noqa: E402
 
-tag = sys.argv[1]
+rnd, btag, ptag = sys.argv[1:4]
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+HEAD = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+STAMP = f"(commit {HEAD}; 1 x MI355X box of the gpurun pool, ROCm 7.2, rocprofv3)"
 
 
 def last_json(name):
     return [l for l in open(os.path.join(G, name)).read().strip().split("\n") if l.startswith("{")][-1]
 
 
-def summary(d):
+def captured(fn, *a):
     buf = io.StringIO()
     with redirect_stdout(buf):
-        sr.main(os.path.join(G, d))
+        fn(*a)
     return buf.getvalue()
 
 
-def counters_of(d):
-    s = summary(d)
-    return s[s.index("## counters"):]
+def counters(d):
+    out = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    for f in glob.glob(os.path.join(G, d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            a = out[sr.short(r["Kernel_Name"])][r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return out
 
 
-for src, dst in (("c2", "config2"), ("c3", "config3"), ("c4", "config4"), ("c5", "config5"), ("c2_ws1", "config2_ws1_rccl"),
-                 ("c4_ws1", "config4_ws1_rccl"), ("c2_pcie", "config2_pcie")):
-    open(os.path.join(P, f"r02_bench_{dst}.json"), "w").write(last_json(f"{tag}_{src}.log") + "\n")
-stats = glob.glob(os.path.join(G, f"prof_{tag}_trace", "**", "*kernel_stats.csv"), recursive=True)[0]
-shutil.copy(stats, os.path.join(P, "r02_kernel_stats.csv"))
-b, u = json.loads(last_json(f"prof_{tag}_trace.log")), json.loads(last_json(f"{tag}_c2.log"))
+# ---- bench lines ------------------------------------------------------------------------------------------------------------------
+lines = {"c2": "config2", "c2_pcie": "config2_pcie", "c3": "config3", "c4": "config4", "c5": "config5", "c4job": "config4_job",
+         "c5job": "config5_job", "c2_ws1": "config2_ws1_rccl", "c4job_ws1": "config4_job_ws1_rccl", "c5job_ws1": "config5_job_ws1_rccl"}
+bench = {}
+for src, dst in lines.items():
+    path = os.path.join(G, f"{btag}_{src}.log")
+    if os.path.exists(path):
+        bench[src] = json.loads(last_json(f"{btag}_{src}.log"))
+        open(os.path.join(P, f"{rnd}_bench_{dst}.json"), "w").write(json.dumps(bench[src]) + "\n")
+
+# ---- kernel traces -------------------------------------------------------------------------------------------------------------------
+stats = glob.glob(os.path.join(G, f"prof_{ptag}_trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(P, f"{rnd}_kernel_stats.csv"))
+b = json.loads(last_json(f"prof_{ptag}_trace.log"))
 tot = n = 0
-for f in glob.glob(os.path.join(G, f"prof_{tag}_trace", "**", "*kernel_trace.csv"), recursive=True):
+for f in glob.glob(os.path.join(G, f"prof_{ptag}_trace", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         if "conv3x3_wino4" in r["Kernel_Name"]:
             tot += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             n += 1
-trace = summary(f"prof_{tag}_trace")
-open(os.path.join(P, "r02_kernel_trace.md"), "w").write(
-    "# Round 2 — rocprofv3 kernel trace, bench.py --no-cpu --no-secondary --steps 10 --warmup 2 (1 MI355X, config 2, final round-2 binary)\n\n"
-    "`tools/collect_profiles.sh`: `cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d … -- python3 bench.py --no-cpu "
-    "--no-secondary --steps 10 --warmup 2` (19 steps traced: 2 warm-up + 10 timed + 7 event-instrumented).\n"
+u = bench.get("c2", b)
+open(os.path.join(P, f"{rnd}_kernel_trace.md"), "w").write(
+    f"# {rnd} — rocprofv3 kernel trace of `bench.py --no-cpu --steps 10 --warmup 2` (config 2, with the 1080p pixel-kernel leg) {STAMP}\n\n"
+    "`tools/collect_profiles.sh <tag> trace`: `cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d … -- python3 bench.py --no-cpu "
+    "--steps 10 --warmup 2` (2 warm-up + 10 timed + 7 event-instrumented steps, then the frame-sized pixel kernels of the video / guide\n"
+    "post-pass on 8 x 1080p: `resize_area*`, `warp_blend_u8*`, `quantize_u8*`, `mask_composite`, `resize_*`).\n"
     f"bench line of the same (profiled) run: {b['value']:.2f} Mpixels/s, {b['ms_per_step']:.3f} ms/step, roofline.avg_launch_ms "
-    f"{b['roofline']['avg_launch_ms']:.4f} (HIP events); unprofiled run of the same binary: profiles/r02_bench_config2.json "
+    f"{b['roofline']['avg_launch_ms']:.4f} (HIP events); unprofiled run of the same binary: profiles/{rnd}_bench_config2.json "
     f"({u['value']:.2f} Mpixels/s, {u['ms_per_step']:.3f} ms/step, avg_launch_ms {u['roofline']['avg_launch_ms']:.4f}).\n"
     f"conv3x3_wino4_kernel over all dispatches: {tot:,.1f} us / {n} dispatches = {tot / n:.1f} us per launch under the profiler "
-    "(16 launches per step: 8 merged content+style encoder layers, 8 decoder layers).\n\n" + trace)
+    "(16 launches per step: 8 merged content+style encoder layers, 8 decoder layers).\n\n" + captured(sr.main, os.path.join(G, f"prof_{ptag}_trace")))
+open(os.path.join(P, f"{rnd}_gaps.md"), "w").write(
+    f"# {rnd} — idle time between the kernels of the config-2 step {STAMP}\n\nFrom the same trace as {rnd}_kernel_trace.md (`tools/gap_report.py`, "
+    "the first 100 dispatches = weight packing and warm-up skipped): start of the next kernel minus end of the previous one.\n\n"
+    + captured(gap_report.main, os.path.join(G, f"prof_{ptag}_trace"), 100))
+for cfg in (3, 4, 5):
+    d = f"prof_{ptag}_cfg{cfg}_trace"
+    if os.path.isdir(os.path.join(G, d)):
+        bl = json.loads(last_json(d + ".log"))
+        open(os.path.join(P, f"{rnd}_kernel_trace_config{cfg}.md"), "w").write(
+            f"# {rnd} — rocprofv3 kernel trace of `bench.py --config {cfg} --no-cpu --no-secondary --steps 5 --warmup 1` {STAMP}\n\n"
+            f"bench line of the profiled run: {bl['value']:.2f} Mpixels/s, {bl['ms_per_step']:.3f} ms/step, matrix pipe {bl['roofline']['frac']:.4f}; "
+            f"`<…, 1>` = the 16 x 16 tile geometry, `<…, 0>` = 8 x 32 (csrc/conv_wino4.hip).\n\n" + captured(sr.main, os.path.join(G, d)))
+d = f"prof_{ptag}_all_kernels"
+if os.path.isdir(os.path.join(G, d)):
+    open(os.path.join(P, f"{rnd}_all_kernels.md"), "w").write(
+        f"# {rnd} — every kernel of the product library in one trace: `tools/all_kernels.py` {STAMP}\n\n"
+        "`cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d … -- python3 tools/all_kernels.py`: every public entry point at shapes\n"
+        "that select each launch form (both tile geometries, persistent / one-tile, up-sampling, uint8 / float first layer, NHWC / NCHW statistics,\n"
+        "every INTER_AREA form ...).  Not in this trace: the `BIG` instantiations of conv3x3_wino4_kernel (per-image tensors >= 2 GiB; exercised by\n"
+        "tests/test_gpu_parity.py::test_conv_tensors_above_two_gib).  `__amd_rocclr_*` / `at::native::*` rows are the script's own tensor set-up.\n\n"
+        + open(os.path.join(G, d + ".log")).read().strip().split("\n")[-1] + "\n\n" + captured(sr.main, os.path.join(G, d)))
 
+# ---- counters ----------------------------------------------------------------------------------------------------------------------
+pmc = [f"# {rnd} — rocprofv3 PMC passes, one counter set per run, config 2 unless stated {STAMP}\n",
+       "`tools/collect_profiles.sh <tag> pmc waits`; `bench.py --no-cpu --no-secondary --steps 5 --warmup 1` under `rocprofv3 --pmc <counters> "
+       "--kernel-trace` (never combined with other trace domains).  FETCH_SIZE / WRITE_SIZE in KB per dispatch; 2 x FETCH_SIZE + WRITE_SIZE = "
+       "L2-miss traffic (gfx950 reports half the bytes of wide coalesced reads; it includes what the 256 MB Infinity Cache serves).\n"]
+for part in ("fetch", "write", "sq"):
+    d = os.path.join(G, f"prof_{ptag}_{part}")
+    if os.path.isdir(d):
+        s = captured(sr.main, d)
+        pmc.append(f"\n## pass `{part}`\n\n" + s[s.index("## counters") + len("## counters (average per dispatch)\n"):])
+sq = counters(f"prof_{ptag}_sq")
+rows = []
+for k, c in sorted(sq.items()):
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and "conv3x3_wino4" in k:
+        busy = c["SQ_VALU_MFMA_BUSY_CYCLES"][1] / (c["GRBM_GUI_ACTIVE"][1] / 8 * 1024)     # per-SIMD busy cycles / (chip cycles x 1024 SIMDs)
+        vm = c["SQ_INSTS_VALU"][1] / c["SQ_INSTS_MFMA"][1]
+        lds = c["SQ_LDS_BANK_CONFLICT"][1] / max(c["SQ_LDS_IDX_ACTIVE"][1], 1)
+        rows.append(f"| `{k}` | {c['SQ_INSTS_MFMA'][0]} | {busy:.4f} | {vm:.2f} | {c['SQ_INSTS_MFMA'][1] / c['SQ_INSTS_MFMA'][0] * 4096 / 1e9:.3f} | {100 * lds:.1f} % |")
+if rows:
+    pmc.append("\n## derived (pass `sq`)\n\nmatrix-pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); executed GFLOP = SQ_INSTS_MFMA x 4096 flop\n\n"
+               "| kernel | dispatches | matrix pipe busy | SQ_INSTS_VALU / SQ_INSTS_MFMA | executed GFLOP per dispatch | LDS bank-conflict cycles |\n|---|---|---|---|---|---|\n" + "\n".join(rows) + "\n")
+w = {cfg: (counters(f"prof_{ptag}_cfg{cfg}_waits"), counters(f"prof_{ptag}_cfg{cfg}_tcc")) for cfg in (2, 3)}
+rows = []
+for cfg, (wa, tc) in w.items():
+    for k in sorted(wa):
+        if "conv3x3_wino4_kernel<0, 0, true" in k and k in tc:
+            a, t = wa[k], tc[k]
+            rows.append(f"| {cfg} | `{k}` | {a['SQ_WAVE_CYCLES'][0]} | {a['SQ_WAIT_ANY'][1] / a['SQ_WAVE_CYCLES'][1]:.4f} | "
+                        f"{a['SQ_WAIT_INST_ANY'][1] / a['SQ_WAVE_CYCLES'][1]:.4f} | {t['TCC_HIT_sum'][1] / (t['TCC_HIT_sum'][1] + t['TCC_MISS_sum'][1]):.4f} | "
+                        f"{t['TCC_MISS_sum'][1] / t['TCC_MISS_sum'][0]:.3g} |")
+if rows:
+    pmc.append("\n## is the larger feature map's extra L2-miss traffic free?  (passes `cfg{2,3}_waits`, `cfg{2,3}_tcc`; direct persistent launches)\n\n"
+               "Config 3 (2048 x 2048) misses the 4 MB L2s more often than config 2 (the 256-channel layers work on 512 x 512 maps: a round of 64 resident "
+               "workgroups per XCD streams 5.6 MB of halos beside its 3.1 MB of weights), but its waves spend no larger share of their cycles waiting: the "
+               "misses are served by the Infinity Cache behind the second wave of each SIMD, and the same-box bench lines run config 3 at a matrix-pipe "
+               "fraction no lower than config 2's.\n\n"
+               "| config | kernel | dispatches | SQ_WAIT_ANY / SQ_WAVE_CYCLES | SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES | L2 hit rate TCC_HIT / (HIT + MISS) | TCC_MISS per dispatch |\n"
+               "|---|---|---|---|---|---|---|\n" + "\n".join(rows) + "\n")
+open(os.path.join(P, f"{rnd}_pmc.md"), "w").write("\n".join(pmc))
 
-def last_step(d, counter):
-    rows = [r for f in glob.glob(os.path.join(G, d, "**", "*counter_collection.csv"), recursive=True) for r in csv.DictReader(open(f))]
-    rows = [r for r in rows if r["Counter_Name"] == counter and "conv3x3_wino4" in r["Kernel_Name"]]
-    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    return rows[-16:]
-
-
-names = ["conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv3_4", "conv4_1", "dec1", "dec2", "dec3", "dec4", "dec5",
-         "dec6", "dec7", "dec8"]
-tab = ("## per conv3x3 launch of the last step (MB: 2 x FETCH_SIZE, WRITE_SIZE); encoder launches carry content + style\n\n"
-       "| layer | fetch MB | write MB |\n|---|---|---|\n")
-for nm, a, w in zip(names, last_step(f"prof_{tag}_fetch", "FETCH_SIZE"), last_step(f"prof_{tag}_write", "WRITE_SIZE")):
-    tab += f"| {nm} | {2 * float(a['Counter_Value']) / 1024:.1f} | {float(w['Counter_Value']) / 1024:.1f} |\n"
-
-# ratios quoted in the header, from the sq pass
-agg = {}
-for f in glob.glob(os.path.join(G, f"prof_{tag}_sq", "**", "*counter_collection.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = sr.short(r["Kernel_Name"])
-        agg.setdefault(k, {}).setdefault(r["Counter_Name"], [0, 0.0])
-        agg[k][r["Counter_Name"]][0] += 1
-        agg[k][r["Counter_Name"]][1] += float(r["Counter_Value"])
-
-
-def ratio(k, a, bb, scale=1.0):
-    return agg[k][a][1] / (agg[k][bb][1] * scale)
-
-
-ks = ["conv3x3_wino4_kernel<0, 0, true, false>", "conv3x3_wino4_kernel<1, 0, true, false>", "conv3x3_wino4_kernel<0, 0, false, false>"]
-ks = [k if k in agg else k.replace(", false>", ">") for k in ks]
-busy = [ratio(k, "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", 128.0) for k in ks]
-vpm = [ratio(k, "SQ_INSTS_VALU", "SQ_INSTS_MFMA") for k in ks]
-lds = [ratio(k, "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE") for k in ks]
-edge = {k: ratio(k, "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", 128.0) for k in agg if k.startswith("conv_first") or k.startswith("conv_last")}
-fetch_last = [r for f in glob.glob(os.path.join(G, f"prof_{tag}_fetch", "**", "*counter_collection.csv"), recursive=True)
-              for r in csv.DictReader(open(f)) if r["Counter_Name"] == "FETCH_SIZE" and "conv_last_kernel" in r["Kernel_Name"]]
-cl_mb = 2 * sum(float(r["Counter_Value"]) for r in fetch_last) / len(fetch_last) / 1024
-old = subprocess.run(["git", "show", "HEAD:profiles/r02_pmc.md"], capture_output=True, text=True, cwd=ROOT).stdout
-keep = old[old.index("## 256->256 @256^2 probe"):old.index("## per conv3x3 launch of the last step")]
-hdr = ("# Round 2 — rocprofv3 PMC passes (separate runs) of bench.py --no-cpu --no-secondary --steps 5 --warmup 1 (config 2, final round-2 binary)\n\n"
-       "`tools/collect_profiles.sh` (each pass: `rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py …`, nothing else traced); summarised by `tools/refresh_profiles.py`.\n"
-       "Units: FETCH_SIZE / WRITE_SIZE in KB per dispatch (FETCH_SIZE is doubled in profiles/pmc_traffic.json: gfx950 counts half the bytes of wide "
-       "coalesced reads; it counts every L2 miss, including those the Infinity Cache serves).  SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 "
-       f"SIMDs) = matrix-pipe busy fraction: {busy[0]:.3f} (persistent, direct source), {busy[1]:.3f} (persistent, fused 2x upsample), {busy[2]:.3f} "
-       "(one-tile form: dec1); " + ", ".join(f"{k.split('<')[0]} {v:.2f}" for k, v in sorted(edge.items())) + ".  SQ_INSTS_VALU / SQ_INSTS_MFMA = "
-       f"{vpm[0]:.1f} / {vpm[1]:.1f} / {vpm[2]:.1f}: {vpm[0] - 1:.1f} / {vpm[1] - 1:.1f} / {vpm[2] - 1:.1f} plain vector instructions per MFMA over whole "
-       "launches (3.2 inside the main loop; the rest is the per-tile epilogue and prologue, which weighs most on the cin = 64 layers).  "
-       f"SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = {lds[0]:.2f} / {lds[1]:.2f} / {lds[2]:.2f} with the de-interleaved halo image (the interleaved image "
-       f"of round 1: 0.49 on the 256->256 probe; same probe now 0.08).  conv_last: 2 x FETCH_SIZE = {cl_mb:.0f} MB per launch for 268 MB of input "
-       "(XCD-contiguous tile ranges; the round-1 kernel fetched 323 MB).\n\n")
-body = ("## pass 1: FETCH_SIZE\n" + counters_of(f"prof_{tag}_fetch") + "\n## pass 2: WRITE_SIZE\n" + counters_of(f"prof_{tag}_write")
-        + "\n## pass 3: SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA\n"
-        + counters_of(f"prof_{tag}_sq"))
-open(os.path.join(P, "r02_pmc.md"), "w").write(hdr + body.rstrip("\n") + "\n\n" + keep + tab)
-sr.traffic(os.path.join(G, f"prof_{tag}_fetch"), os.path.join(G, f"prof_{tag}_write"), "config2_batch1", os.path.join(P, "pmc_traffic.json"),
-           "profiles/r02_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --no-cpu --no-secondary --steps 5 --warmup 1, round 2 final binary)")
-print("busy", [round(x, 3) for x in busy], "valu/mfma", [round(x, 2) for x in vpm], "lds", [round(x, 3) for x in lds], "edge", edge)
-print("trace:", f"{tot:,.1f} us / {n} = {tot / n:.1f} us; profiled events {b['roofline']['avg_launch_ms']:.4f}")
+# ---- HBM-side traffic per conv3x3 launch (roofline.traffic of the bench lines) ---------------------------------------------------------
+tj = os.path.join(P, "pmc_traffic.json")
+src = f"profiles/{rnd}_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py {{args}}--no-cpu --no-secondary --steps 5 --warmup 1, commit {HEAD})"
+for key, f, wdir, args in (("config2_batch1", f"prof_{ptag}_fetch", f"prof_{ptag}_write", ""),
+                           ("config3_batch1", f"prof_{ptag}_cfg3_fetch", f"prof_{ptag}_cfg3_write", "--config 3 "),
+                           ("config4_batch1", f"prof_{ptag}_cfg4_fetch", f"prof_{ptag}_cfg4_write", "--config 4 "),
+                           ("config5_batch1", f"prof_{ptag}_cfg5_fetch", f"prof_{ptag}_cfg5_write", "--config 5 ")):
+    if os.path.isdir(os.path.join(G, f)) and os.path.isdir(os.path.join(G, wdir)):
+        captured(sr.traffic, os.path.join(G, f), os.path.join(G, wdir), key, tj, src.format(args=args))
+print("profiles refreshed for", rnd, "at", HEAD)
+for f in sorted(os.listdir(P)):
+    if f.startswith(rnd):
+        print("  ", f, os.path.getsize(os.path.join(P, f)))
