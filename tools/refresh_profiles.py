@@ -152,7 +152,9 @@ src = f"profiles/{rnd}_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
 for key, f, wdir, args in (("config2_batch1", f"prof_{ptag}_fetch", f"prof_{ptag}_write", ""),
                            ("config3_batch1", f"prof_{ptag}_cfg3_fetch", f"prof_{ptag}_cfg3_write", "--config 3 "),
                            ("config4_batch1", f"prof_{ptag}_cfg4_fetch", f"prof_{ptag}_cfg4_write", "--config 4 "),
-                           ("config5_batch1", f"prof_{ptag}_cfg5_fetch", f"prof_{ptag}_cfg5_write", "--config 5 ")):
+                           ("config5_batch1", f"prof_{ptag}_cfg5_fetch", f"prof_{ptag}_cfg5_write", "--config 5 "),
+                           ("config4_batch2", f"prof_{ptag}_cfg4b2_fetch", f"prof_{ptag}_cfg4b2_write", "--config 4 --batch 2 "),
+                           ("config5_batch2", f"prof_{ptag}_cfg5b2_fetch", f"prof_{ptag}_cfg5b2_write", "--config 5 --batch 2 ")):
     if os.path.isdir(os.path.join(G, f)) and os.path.isdir(os.path.join(G, wdir)):
         captured(sr.traffic, os.path.join(G, f), os.path.join(G, wdir), key, tj, src.format(args=args))
 print("profiles refreshed for", rnd, "at", HEAD)
