@@ -160,6 +160,13 @@ def gather_frames(local, n_items, dst=0, group=None, async_op=False, counts=None
     if local.shape[0] < mx:
         pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))])
     pad = pad.contiguous()
+    # gloo gathers CPU tensors only: device blocks then travel as host copies (single-GPU rehearsals of the multi-rank path and
+    # the CPU tests; a production group carries device tensors over RCCL - callers that must not degrade pass
+    # require_transport="rccl" to the job drivers, bench.py refuses to report otherwise)
+    via_host = pad.is_cuda and device_transport(pad, group) != "rccl"
+    dev = pad.device
+    if via_host:
+        pad = pad.cpu()
     out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     CALLS["gather"] += 1
     work = dist.gather(pad, out, dst=dst, group=group, async_op=async_op)
@@ -169,6 +176,7 @@ def gather_frames(local, n_items, dst=0, group=None, async_op=False, counts=None
             work.wait()
         if rank != dst:
             return None
-        return torch.cat([o[:c] for o, c in zip(out, counts)])
+        res = torch.cat([o[:c] for o, c in zip(out, counts)])
+        return res.to(dev) if via_host else res
 
     return finish if async_op else finish()

@@ -547,7 +547,7 @@ class Ctx:
         """Connection setup of the device transport (RCCL builds its communicator on first use) stays out of every timed region."""
         if self.use_dist:
             probe = torch.zeros((batch, 8, 8, 3), dtype=torch.uint8, device=self.device)
-            sh.gather_frames(probe if self.transport == "rccl" else probe.cpu(), n_job, dst=0, counts=[batch] * self.world)
+            sh.gather_frames(probe, n_job, dst=0, counts=[batch] * self.world)
             self.barrier()
 
     def finish(self):
@@ -579,9 +579,7 @@ def main_job(args, ctx):
     engine = engine_mod.AdaINEngine(weights[0], weights[1], device)
     style = torch.from_numpy(synth.image(4, 1, hs, ws)).to(device)
     style_cache = {}
-    via_rccl = ctx.use_dist and ctx.transport == "rccl"
-    if ctx.use_dist and not via_rccl:
-        raise SystemExit("bench.py --job: the job driver gathers device tensors; a single-GPU rehearsal over gloo is not supported here")
+    via_rccl = ctx.use_dist and ctx.transport == "rccl"       # (--rehearse: ranks share a GPU, the gather moves host copies over gloo)
 
     def make_job(frames, masks, host_result=None):
         def job():
@@ -643,6 +641,8 @@ def main_job(args, ctx):
                          "per_rank": per_rank, "ms_per_frame": round(sec_per_job * 1e3 / max(shard), 4)}
         if args.n1_value > 0:
             result["job"]["efficiency_vs_n1"] = round(value / (args.n1_value * world), 4)
+        if args.rehearse:
+            result["rehearsal"] = {"ranks_share_a_gpu": ctx.shared_gpu, "note": "not a multi-GPU measurement"}
         if pcie is not None:
             result["pcie_inclusive"] = pcie
         if world == 1 and not args.no_secondary:
@@ -681,8 +681,7 @@ def main():
         # quantiser / mask composite); whole jobs through the sharded driver are `--job`
         out = step.run(to_u8=use_dist)
         if use_dist:                                  # the path's one collective: finished uint8 frames -> rank 0
-            u8 = step.u8 if transport == "rccl" else step.u8.cpu()
-            pending.append(sh.gather_frames(u8, n_job, dst=0, async_op=True))
+            pending.append(sh.gather_frames(step.u8, n_job, dst=0, async_op=True))
             if len(pending) > 2:                      # at most two gathers in flight: step k's overlaps step k+1's compute
                 gathered[0] = pending.pop(0)()
         return out
@@ -712,10 +711,9 @@ def main():
     # one isolated gather (nothing else in flight) for the transport's own cost
     gather_ms = None
     if use_dist:
-        u8 = step.u8 if transport == "rccl" else step.u8.cpu()
         barrier()
         g0 = time.perf_counter()
-        sh.gather_frames(u8, n_job, dst=0)
+        sh.gather_frames(step.u8, n_job, dst=0)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
 
