@@ -244,7 +244,8 @@ class FrameFeeder:
                 ready = None
                 if not self.cuda:
                     content = items if isinstance(items, torch.Tensor) else torch.stack(items)
-                    mask = torch.stack(mask) if mask is not None else None
+                    if mask is not None and all(m.shape == mask[0].shape for m in mask):
+                        mask = torch.stack(mask)
                 else:
                     if self.h2d_done[s] is not None:
                         self.h2d_done[s].synchronize()                   # the slot's previous uploads have left its pinned buffers
@@ -274,8 +275,8 @@ class FrameFeeder:
                                 mask.record_stream(self.compute_stream)
                             elif self._uniform(mask):
                                 mask = self._stage(s, "mask", mask)
-                            else:
-                                mask = self._upload(torch.stack([m.cpu() for m in mask]))
+                            else:                                        # masks of several sizes: one upload each, composited per frame
+                                mask = [m if m.is_cuda else self._upload(m) for m in mask]
                             staged = True
                         if staged:
                             ready = torch.cuda.Event()
@@ -532,7 +533,10 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
                 out = engine.stylize_depth(content, [d.to(dev, torch.float32) for d in batch.depth], depth_offset, depth_prominence)
             else:
                 out = engine.stylize(content, alpha)
-            if batch.mask is not None:
+            if isinstance(batch.mask, list):       # masks of different sizes inside one sub-batch: composite frame by frame
+                out = torch.cat([engine.composite(content[k:k + 1], out[k:k + 1], m.to(dev).float().unsqueeze(0))
+                                 for k, m in enumerate(batch.mask)])
+            elif batch.mask is not None:
                 out = engine.composite(content, out, batch.mask.to(dev).float())
             u8 = engine.to_u8(out)
             feeder.release(batch)

@@ -362,3 +362,22 @@ def test_video_directory_job_never_strands_a_rank(tmp_path, mode):
     else:
         assert outs == ["RuntimeError", "RuntimeError"]
         assert os.listdir(tmp_path / "out_noflow") == []
+
+
+def test_masks_of_mixed_sizes_inside_one_sub_batch():
+    """Masks may come at another resolution than the views (the reference nearest-resizes them, test.py:222-236) and then need
+    not share one size inside a sub-batch: the driver composites those frame by frame - same result as one frame at a time."""
+    import torch.nn.functional as F
+
+    class Engine(StubEngine):
+        def composite(self, content, stylized, masks):
+            c = self._f32(content)
+            m = F.interpolate(masks.float(), size=c.shape[-2:], mode="nearest")
+            return c * (1 - m) + stylized * m
+
+    frames, masks = _u8_inputs(4)
+    masks[1] = masks[1][:, :6, :10]
+    style = torch.full((1, 3, 4, 4), 0.3)
+    out, _ = jobs.stylize_frames_sharded(Engine(), frames, style, masks=masks, sub_batch=4)
+    one = torch.cat([jobs.stylize_frames_sharded(Engine(), [frames[k]], style, masks=[masks[k]], sub_batch=1)[0] for k in range(4)])
+    assert torch.equal(out, one)
