@@ -795,6 +795,18 @@ static void w4_launch_geo(int geo, dim3 grid, hipStream_t s, const ConvArgs& a, 
 static void w4_launch(int src_mode, bool persist, bool big, int geo, dim3 grid, hipStream_t s, const ConvArgs& a, const ConvSegs& m,
                       int items, int prio) {
     const bool up = src_mode == SRC_UP2X;
+#ifdef ADAIN_DIAG
+    // timing-only ablations of the PERSISTENT form inside whole passes (wrong results by construction; bench.py --diag-lib with
+    // ADAIN_W4_PDIAG = 8: no halo loads or stores in the main loop, 10: no halo loads, 11: no halo stores): what the halo staging
+    // costs the step, i.e. the most a direct-to-LDS staging (`buffer_load ... lds`) could win
+    static const int pdiag = tune_env("ADAIN_W4_PDIAG", 0);
+    if (persist && !big && geo == 0 && (pdiag == 8 || pdiag == 10 || pdiag == 11)) {
+#define W4_PDIAG_CASE(D) if (pdiag == D) { if (up) hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_UP2X, D, true>), grid, dim3(256), 0, s, a, m, items, prio); \
+                                           else hipLaunchKernelGGL((conv3x3_wino4_kernel<SRC_DIRECT, D, true>), grid, dim3(256), 0, s, a, m, items, prio); return; }
+        W4_PDIAG_CASE(8) W4_PDIAG_CASE(10) W4_PDIAG_CASE(11)
+#undef W4_PDIAG_CASE
+    }
+#endif
     if (persist) {
         if (big) up ? w4_launch_geo<SRC_UP2X, true, true>(geo, grid, s, a, m, items, prio) : w4_launch_geo<SRC_DIRECT, true, true>(geo, grid, s, a, m, items, prio);
         else up ? w4_launch_geo<SRC_UP2X, true, false>(geo, grid, s, a, m, items, prio) : w4_launch_geo<SRC_DIRECT, true, false>(geo, grid, s, a, m, items, prio);
