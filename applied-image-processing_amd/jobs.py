@@ -69,13 +69,14 @@ def as_frame(x):
     ``"f32"`` = an already transformed float tensor [3,h,w] in [0,1] (a fourth channel is dropped)."""
     if not isinstance(x, (torch.Tensor, np.ndarray)):          # a PIL image
         if getattr(x, "mode", None) == "RGB":
-            x = np.asarray(x)
+            x = np.array(x)                                   # (a writable copy: np.asarray of a PIL image is read-only)
         else:
             from .AdaIN.test import _to_tensor
 
             x = _to_tensor(x)
     if isinstance(x, np.ndarray):
-        x = torch.from_numpy(np.ascontiguousarray(x))
+        x = np.ascontiguousarray(x)
+        x = torch.from_numpy(x if x.flags.writeable else x.copy())
     if x.dtype == torch.uint8:
         if x.dim() != 3 or x.shape[2] != 3:
             raise ValueError(f"a uint8 frame must be [h,w,3], got {tuple(x.shape)}")
