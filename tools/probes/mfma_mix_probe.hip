@@ -200,6 +200,14 @@ int main() {
     run<13, 0, 0, 0, 1>("");
     run<13, 4, 1, 3, 1>("design (d): one wave per SIMD with two channel tiles = half the vector instructions per MFMA");
     run<13, 8, 1, 6, 1>("(d) with twice the LDS reads and memory loads");
+    // round 3, DESIGN.md section 8 (e): F(4x4,3x3) with two 32-channel tiles per wave at ONE wave per SIMD: per 8 MFMAs 18 vector
+    // instructions (2.25 per MFMA), 2.7 patch reads (24 per 72 MFMAs), 0.5 staging writes, 2 weight + 0.5 halo loads.  Multiply its
+    // rate by 4 (2.25 multiplies per output) and today's mix <25, 4, 1, 3> at two waves by 3 to compare per OUTPUT.
+    run<18, 3, 1, 3, 1>("design (e): F(4x4,3x3), two channel tiles per wave, one wave per SIMD");
+    run<18, 3, 0, 2, 1>("(e) without staging traffic");
+    run<18, 0, 0, 0, 1>("(e) vector instructions only");
+    run<16, 3, 1, 3, 1>("(e) with a 2.0-per-MFMA transform");
+    run<18, 3, 1, 3, 2>("(e)'s mix at two waves per SIMD (does not fit the registers: reference only)");
     run_pair<25>("design (c): one wave of a SIMD transforms for both");
     run_pair<0>("the same without vector instructions");
     return 0;
