@@ -789,8 +789,10 @@ static int pick_geo(const ConvSeg* segs, int count) {
 
 template <int MODE, bool PERSIST, bool BIG>
 static void w4_launch_geo(int geo, dim3 grid, hipStream_t s, const ConvArgs& a, const ConvSegs& m, int items, int prio) {
-    if (geo) hipLaunchKernelGGL((conv3x3_wino4_kernel<MODE, 0, PERSIST, BIG, 1>), grid, dim3(256), 0, s, a, m, items, prio);
-    else hipLaunchKernelGGL((conv3x3_wino4_kernel<MODE, 0, PERSIST, BIG, 0>), grid, dim3(256), 0, s, a, m, items, prio);
+    if constexpr (!BIG) {       // (per-tile descriptors - tensors of 2 GiB and more - exist for the default geometry only: see pick_geo's callers)
+        if (geo) { hipLaunchKernelGGL((conv3x3_wino4_kernel<MODE, 0, PERSIST, BIG, 1>), grid, dim3(256), 0, s, a, m, items, prio); return; }
+    }
+    hipLaunchKernelGGL((conv3x3_wino4_kernel<MODE, 0, PERSIST, BIG, 0>), grid, dim3(256), 0, s, a, m, items, prio);
 }
 static void w4_launch(int src_mode, bool persist, bool big, int geo, dim3 grid, hipStream_t s, const ConvArgs& a, const ConvSegs& m,
                       int items, int prio) {
@@ -822,7 +824,8 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     ConvSegs m{};
     m.count = 1;
     m.s[0] = ConvSeg{a.in, a.out, a.n, a.H, a.W, a.Hs, a.Ws, 0, 0, 0};
-    const int geo = a.dbg ? 0 : pick_geo(m.s, 1);               // the stamp / timing-only builds exist for the default geometry
+    const bool big = wino4_big(a);
+    const int geo = (a.dbg || big) ? 0 : pick_geo(m.s, 1);      // the stamp / timing-only and the >= 2 GiB builds exist for the default geometry
     a.tiles_x = (a.W + tile_w(geo) - 1) / tile_w(geo);
     a.tiles_y = (a.H + tile_h(geo) - 1) / tile_h(geo);
     m.s[0].tiles_x = a.tiles_x; m.s[0].tiles_y = a.tiles_y;
@@ -840,7 +843,6 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
     const bool persist_ok = a.cin <= persist_env && a.cin >= 2 * W4_KR && pgrid >= 8 && blocks >= 2 * pgrid;
     const bool persist = !a.dbg && persist_ok;
     const int items = (int)blocks;
-    const bool big = wino4_big(a);
     m.ctg = walk_group(a.cin, a.cout);
     m.stagger = tune_env("ADAIN_W4_STAGGER", W4_STAGGER);
     if (persist) {
@@ -879,7 +881,11 @@ int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int c
     long long total = 0;
     bool big = false;
     ConvArgs a = layer;
-    const int geo = pick_geo(segs, count);                       // one geometry per launch: the one with fewer tiles over all segments
+    for (int i = 0; i < count; ++i) {
+        a.n = segs[i].n; a.H = segs[i].H; a.W = segs[i].W; a.Hs = segs[i].Hs; a.Ws = segs[i].Ws;
+        big = big || wino4_big(a);
+    }
+    const int geo = big ? 0 : pick_geo(segs, count);             // one geometry per launch: the one with fewer tiles over all segments
     for (int i = 0; i < count; ++i) {
         a.in = segs[i].in; a.out = segs[i].out; a.n = segs[i].n;
         a.H = segs[i].H; a.W = segs[i].W; a.Hs = segs[i].Hs; a.Ws = segs[i].Ws;

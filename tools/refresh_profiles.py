@@ -13,7 +13,6 @@ import glob
 import io
 import json
 import os
-import re
 import shutil
 import subprocess
 import sys
