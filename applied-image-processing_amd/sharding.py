@@ -167,7 +167,10 @@ def gather_frames(local, n_items, dst=0, group=None, async_op=False, counts=None
     dev = pad.device
     if via_host:
         pad = pad.cpu()
-    out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    # the peers' blocks land in consecutive slices of ONE buffer: with equal block lengths (the usual case) that buffer IS the
+    # result in frame order and nothing is copied on dst
+    buf = pad.new_empty((world * mx,) + tuple(pad.shape[1:])) if rank == dst else None
+    out = [buf[r * mx:(r + 1) * mx] for r in range(world)] if rank == dst else None
     CALLS["gather"] += 1
     work = dist.gather(pad, out, dst=dst, group=group, async_op=async_op)
 
@@ -176,7 +179,7 @@ def gather_frames(local, n_items, dst=0, group=None, async_op=False, counts=None
             work.wait()
         if rank != dst:
             return None
-        res = torch.cat([o[:c] for o, c in zip(out, counts)])
+        res = buf if all(c == mx for c in counts) else torch.cat([o[:c] for o, c in zip(out, counts)])
         return res.to(dev) if via_host else res
 
     return finish if async_op else finish()

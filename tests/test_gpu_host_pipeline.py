@@ -167,3 +167,35 @@ def test_bench_frame_store_is_the_host_generator(rt):
     v = synth.frame_u8_torch(1000, 36, 64, "cuda:0", zero_fraction=0.3, zero_seed=2000).cpu().numpy()
     bg = synth.uniform01(2000, 36 * 64).reshape(36, 64) < 0.3
     assert (v[bg] == 0).all() and 0.2 < bg.mean() < 0.4
+
+
+def test_jobs_random_shapes_host_feeder_vs_direct_engine_calls(rt, engine):
+    """Random frame counts, sizes (both tile geometries, ragged), sub-batch sizes, feeder depths, with / without masks and proximity
+    maps: the job driver fed from pageable host uint8 frames must give exactly the uint8 frames of direct engine calls on
+    device-resident float tensors, frame by frame."""
+    import applied_image_processing_amd.jobs as jobs
+
+    rng = np.random.default_rng(23)
+    style = T(synth.image(700, 1, 64, 80)).cuda()
+    stats = engine.set_style(style).style_stats()
+    for case in range(14):
+        n, h, w = int(rng.integers(1, 7)), int(rng.integers(9, 130)), int(rng.integers(9, 210))
+        sub, depth_slots = int(rng.integers(1, 5)), int(rng.integers(2, 5))
+        kind = case % 3                                                     # 0 plain, 1 masks, 2 proximity maps
+        u8 = [u8img(710 + 10 * case + i, h, w) for i in range(n)]
+        masks = [(f > 90).transpose(2, 0, 1) for f in u8] if kind == 1 else None
+        depths = [synth.smooth_depth(720 + 10 * case + i, h + 3, w + 5) for i in range(n)] if kind == 2 else None
+        got, info = jobs.stylize_frames_sharded(engine, u8, style, masks=masks, depth_maps=depths, depth_offset=0.2, depth_prominence=15,
+                                                sub_batch=sub, prefetch=depth_slots, style_cache={0: stats}, fetch_workers=int(rng.integers(1, 4)))
+        engine.use_style_stats(stats)
+        for i in range(n):
+            c = T(u8[i]).permute(2, 0, 1).float().div(255).unsqueeze(0).cuda()
+            if kind == 2:
+                out = engine.stylize_depth(c, [T(depths[i]).cuda()], 0.2, 15)
+            else:
+                out = engine.stylize(c, 0.5)
+            if kind == 1:
+                out = engine.composite(c, out, T(masks[i]).float().unsqueeze(0).cuda())
+            want = engine.to_u8(out)[0]
+            assert torch.equal(got[i], want), (case, n, h, w, sub, kind, i)
+        assert info["feeder"]["batches"] >= -(-n // sub)
