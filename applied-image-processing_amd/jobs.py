@@ -86,6 +86,19 @@ def as_frame(x):
     return x[:3].to(torch.float32), "f32"
 
 
+# sub_batch=None: frames per sub-batch chosen from the frame size, about two megapixels of content per sub-batch.  Measured on
+# device-resident frames (tools/probes/small_frame_probe.py, frames/s at sub-batches of 1 / 2 / 4 / 8 / 16 / 32): 256 x 456 - the
+# reference's own video shape, content_size = 256 - 1587 / 2164 / 2431 / 2570 / 2590 / 2579; 512 x 912: 611 / 646 / 670 / 671 / 659 /
+# 651; 1080p: 154 / 153 / 151 / 148 / 146 / 145.  Small frames need company to fill the chip (a 256 x 456 frame is 960 tile items
+# for 512 resident workgroups); large ones lose to the L2-miss traffic that grows faster than the batch.
+AUTO_SUB_BATCH_PIXELS = 2.0e6
+MAX_AUTO_SUB_BATCH = 32
+
+
+def auto_sub_batch(h, w):
+    return int(max(1, min(MAX_AUTO_SUB_BATCH, round(AUTO_SUB_BATCH_PIXELS / max(1, h * w)))))
+
+
 class _Batch:
     __slots__ = ("i", "j", "content", "depth", "mask", "ready", "slot")
 
@@ -111,7 +124,9 @@ class FrameFeeder:
     pinned memory or streams."""
 
     def __init__(self, frames, lo, hi, style_of, sub_batch, device, depth_maps=None, masks=None, depth=4, cuts=(), workers=4):
-        self.frames, self.lo, self.hi, self.style_of, self.sub_batch = frames, lo, hi, style_of, max(1, int(sub_batch))
+        self.frames, self.lo, self.hi, self.style_of = frames, lo, hi, style_of
+        self.auto = sub_batch is None          # frames per sub-batch from the frame size (auto_sub_batch), per run of equal-sized frames
+        self.sub_batch = MAX_AUTO_SUB_BATCH if self.auto else max(1, int(sub_batch))
         self.cuts = set(cuts)              # frame indices at which a sub-batch must end (chunk borders of a chunked gather)
         self.device = torch.device(device)
         self.depth_maps, self.masks = depth_maps, masks
@@ -132,7 +147,7 @@ class FrameFeeder:
             self.h2d_done = [None] * self.nslots
             self.consumed = [None] * self.nslots
         self.pool = ThreadPoolExecutor(max_workers=max(1, int(workers)), thread_name_prefix="adain-frame-fetch")
-        self.window = max(2 * self.sub_batch, 2 * max(1, int(workers)))      # frames fetched ahead of the cutter
+        self.window = max(2 * (8 if self.auto else self.sub_batch), 2 * max(1, int(workers)))      # frames fetched ahead of the cutter
         self.thread = threading.Thread(target=self._run, name="adain-frame-feeder", daemon=True)
         self.thread.start()
 
@@ -153,20 +168,30 @@ class FrameFeeder:
                 nxt += 1
             return ahead.pop(0).result()
 
+        def size_of(t, kd):
+            return (t.shape[-3], t.shape[-2]) if kd == "u8" else (t.shape[-2], t.shape[-1])
+
         while k < self.hi:
             i = k
             if block is not None:
+                limit = self.sub_batch
+                if self.auto:
+                    one = block(i, i + 1)
+                    limit = auto_sub_batch(*size_of(one, "u8" if one.dtype == torch.uint8 else "f32"))
                 j = i + 1
-                while j < self.hi and j - i < self.sub_batch and self.style_of[j] == self.style_of[i] and j not in self.cuts:
+                while j < self.hi and j - i < limit and self.style_of[j] == self.style_of[i] and j not in self.cuts:
                     j += 1
                 t = block(i, j)
                 yield i, j, t, ("u8" if t.dtype == torch.uint8 else "f32")
                 k = j
                 continue
             items, kind = [], None
-            while k < self.hi and len(items) < self.sub_batch and self.style_of[k] == self.style_of[i] and not (items and k in self.cuts):
+            limit = self.sub_batch
+            while k < self.hi and len(items) < limit and self.style_of[k] == self.style_of[i] and not (items and k in self.cuts):
                 fr, kd = carry if carry is not None else get(k)
                 carry = None
+                if not items and self.auto:
+                    limit = auto_sub_batch(*size_of(fr, kd))
                 if items and (kd != kind or fr.shape != items[0].shape or fr.device != items[0].device):
                     carry = (fr, kd)          # another size / kind: it opens the next sub-batch
                     break
@@ -188,10 +213,12 @@ class FrameFeeder:
         stack) -> the slot's device buffer, asynchronously on the copy stream (the caller holds the stream context and has made
         the stream wait for the slot's previous consumers).  Returns the device view [len(items), ...]."""
         nb = len(items)
-        shape = (self.sub_batch,) + tuple(items[0].shape)
+        # slot capacity: the fixed sub-batch size, or - automatic sub-batches - this batch's own length (constant over a run of
+        # equal-sized frames; the buffers are re-made when a longer batch or another frame size comes)
+        shape = (nb if self.auto else self.sub_batch,) + tuple(items[0].shape)
         key = (s, name)
         pin = self.pinned.get(key)
-        if pin is None or pin.shape != shape or pin.dtype != items[0].dtype:
+        if pin is None or tuple(pin.shape[1:]) != shape[1:] or pin.shape[0] < nb or pin.dtype != items[0].dtype:
             pin = self.pinned[key] = torch.empty(shape, dtype=items[0].dtype, pin_memory=True)
             self.dev[key] = torch.empty(shape, dtype=items[0].dtype, device=self.device)
         pin_np = pin.numpy()
@@ -421,7 +448,7 @@ def _elapsed(engine, a, b):
 
 
 def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, depth_maps=None, depth_offset=0.15,
-                           depth_prominence=20, masks=None, post=None, sub_batch=4, group=None, dst=0, gather=True,
+                           depth_prominence=20, masks=None, post=None, sub_batch=None, group=None, dst=0, gather=True,
                            require_transport=None, style_cache=None, out_hw=None, gather_chunks=1, agree=True, sink=None,
                            prefetch=4, host_out=None, fetch_workers=4):
     """Stylises ``frames`` (a sequence indexed lazily: a rank only ever touches its own block; an element is a decoded
@@ -436,6 +463,8 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
     depth_maps      optional sequence of [h0,w0] proximity maps, one per frame -> depth-aware blend (test.py:52-71) with
                     ``depth_offset`` / ``depth_prominence``; otherwise the ``alpha`` blend (test.py:74-81).
     masks           optional sequence of [1|3,hm,wm] masks -> content-mask composite (test.py:222-236).
+    sub_batch       frames per sub-batch; None (default) = chosen from the frame size, about two megapixels per sub-batch
+                    (``auto_sub_batch``: 16 frames of 256 x 456, 4 of 512 x 912, 1 of 1080p - measured optima).
     post            optional ``f(u8_block) -> u8_block`` applied per sub-batch on the owning rank BEFORE the gather
                     (frame-local work such as the INTER_AREA resize, so the gather moves the small frames).
     sink            optional ``f(i, j, u8_block)`` called with every finished sub-batch (frames i..j-1) on the owning rank.
@@ -641,7 +670,7 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
 
 
 def video_style_transfer_sharded(engine, frames, styles, *, flows=None, target_resolution=None, blend_alpha=0.7, depth_maps=None,
-                                 offset=0.30, prominence=20, alpha=0.5, sub_batch=4, group=None, dst=0, require_transport=None,
+                                 offset=0.30, prominence=20, alpha=0.5, sub_batch=None, group=None, dst=0, require_transport=None,
                                  gather_chunks=1):
     """The video caller (reference video/utils.py:297-369) over a frame list: per-frame AdaIN sharded over the ranks (styles
     switching through the clip as ``style_schedule`` says when several are given; depth-aware when ``depth_maps`` are
@@ -669,7 +698,7 @@ def video_style_transfer_sharded(engine, frames, styles, *, flows=None, target_r
 
 
 def precompute_guides_sharded(engine, views, names, output_dir, style, *, masks=None, content_size=512, crop=False, alpha=0.5,
-                              depth_maps=None, depth_offset=0.5, depth_prominence=20, save_ext=".jpg", sub_batch=4, group=None,
+                              depth_maps=None, depth_offset=0.5, depth_prominence=20, save_ext=".jpg", sub_batch=None, group=None,
                               dst=0, write="dst", require_transport=None, writers=4):
     """The guide-image precompute of the reference's Style_3DGS/train.py:86-115 over all training views, sharded: every view
     is resized as ``adain_inference(content_size=...)`` resizes it (test.py:190-200), stylised, composited with its mask
@@ -715,7 +744,7 @@ def precompute_guides_sharded(engine, views, names, output_dir, style, *, masks=
                                               depth_prominence=depth_prominence, masks=masks, sub_batch=sub_batch, group=group, dst=dst,
                                               gather=True, require_transport=require_transport)
             if rank == dst and len(names):
-                step = max(1, sub_batch)
+                step = max(1, sub_batch or auto_sub_batch(*u8.shape[1:3]))
                 for a in range(0, len(names), step):
                     sink.write(u8[a:a + step], [paths[nm] for nm in names[a:a + step]])
     except Exception as e:

@@ -478,7 +478,7 @@ def parse_args():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[] index + 1 (default 2 = configs[1])")
     ap.add_argument("--size", type=int, default=0, help="override content H = W")
     ap.add_argument("--style-size", type=int, default=512)
-    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 1); with --job: frames per sub-batch (default 2: 1080p sub-batches of 2 / 4 / 8 / 16 measured 322.7 / 320.7 / 316.5 / 310.4 Mpixels/s)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 1); with --job: frames per sub-batch (default: chosen by the driver from the frame size, jobs.auto_sub_batch: 1 at 1080p; sub-batches of 1 / 2 / 4 / 8 / 16 measured 319 / 317 / 313 / 307 / 303 Mpixels/s there, while 256 x 456 frames peak at 16)")
     ap.add_argument("--job", action="store_true", help="configs 4 / 5: run the BASELINE job (512 frames / 300 views) strong-scaled over the ranks")
     ap.add_argument("--frames", type=int, default=0, help="--job: frames of the whole job (default 512 / 300)")
     ap.add_argument("--host-frames", action="store_true",
@@ -499,7 +499,7 @@ def parse_args():
     if args.warmup is None:
         args.warmup = 1 if args.job else 3
     if args.batch is None:
-        args.batch = 2 if args.job else 1
+        args.batch = 0 if args.job else 1          # --job: 0 = the driver's automatic sub-batch (about two megapixels: 1 frame at 1080p)
     return args
 
 
@@ -574,6 +574,7 @@ def main_job(args, ctx):
     h, w = SIZES[cfg]
     hs = ws = args.style_size
     n_total = args.frames or JOB_FRAMES[cfg]
+    sub = args.batch or jobs.auto_sub_batch(h, w)          # frames per sub-batch (what the driver picks itself when given None)
     lo, hi = sh.shard_range(n_total, world, rank)
     weights = synth_weights()
     engine = engine_mod.AdaINEngine(weights[0], weights[1], device)
@@ -583,7 +584,7 @@ def main_job(args, ctx):
 
     def make_job(frames, masks, host_result=None):
         def job():
-            res, info = jobs.stylize_frames_sharded(engine, frames, style, alpha=0.5, masks=masks, sub_batch=args.batch, gather=ctx.use_dist,
+            res, info = jobs.stylize_frames_sharded(engine, frames, style, alpha=0.5, masks=masks, sub_batch=args.batch or None, gather=ctx.use_dist,
                                                     require_transport="rccl" if via_rccl and world > 1 else None, style_cache=style_cache,
                                                     out_hw=(h, w), gather_chunks=args.gather_chunks,
                                                     host_out=host_result)      # the finished frames leave the device behind the kernels
@@ -626,17 +627,17 @@ def main_job(args, ctx):
         value = n_total * h * w / 1e6 / sec_per_job
         what = {4: f"configs[3]: video job, {n_total} frames {h}x{w}", 5: f"configs[4]: 3DGS guide-view job, {n_total} views {h}x{w} with masks"}[cfg]
         shard = sh.shard_counts(n_total, world)
-        workload = (f"{what}, one {hs}x{ws} style (statistics cached per rank), sub-batches of {args.batch}, decoded uint8 frames resident in HBM, "
+        workload = (f"{what}, one {hs}x{ws} style (statistics cached per rank), sub-batches of {sub}{' (automatic)' if not args.batch else ''}, decoded uint8 frames resident in HBM, "
                     f"{'mask composite + ' if cfg == 5 else ''}uint8 out; a step = the whole job")
         parallelism = (f"frame sharding x{world}: contiguous blocks {shard if world > 1 else ''} per rank, replicated weights and style statistics, "
                        f"one status word + ONE gather of the uint8 frames to rank 0 per job" if ctx.use_dist else "single GPU, no collective")
         result = base_result(args, ctx, value, sec_per_job * 1e3, workload, parallelism, "strong")
-        step = Step(device, config=cfg, first_frame=0, style_size=args.style_size, batch=args.batch, engine=engine, weights=weights)
+        step = Step(device, config=cfg, first_frame=0, style_size=args.style_size, batch=sub, engine=engine, weights=weights)
         roof, layers, secondary = measure_roofline(step, 5)
         result["roofline"] = roof
         result["secondary"] = secondary
-        result["step_tflops"] = round((step.flops_per_step() / args.batch * n_total) / sec_per_job / 1e12, 2)
-        result["job"] = {"driver": "jobs.stylize_frames_sharded", "frames": n_total, "frames_per_rank": shard, "sub_batch": args.batch,
+        result["step_tflops"] = round((step.flops_per_step() / sub * n_total) / sec_per_job / 1e12, 2)
+        result["job"] = {"driver": "jobs.stylize_frames_sharded", "frames": n_total, "frames_per_rank": shard, "sub_batch": sub,
                          "gathers_per_job": info["gathers"], "gather_chunks": args.gather_chunks, "transport": ctx.transport,
                          "per_rank": per_rank, "ms_per_frame": round(sec_per_job * 1e3 / max(shard), 4)}
         if args.n1_value > 0:
