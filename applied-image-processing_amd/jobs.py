@@ -86,12 +86,12 @@ def as_frame(x):
     return x[:3].to(torch.float32), "f32"
 
 
-# sub_batch=None: frames per sub-batch chosen from the frame size, about two megapixels of content per sub-batch.  Measured on
+# sub_batch=None: frames per sub-batch chosen from the frame size, about three megapixels of content per sub-batch.  Measured on
 # device-resident frames (tools/probes/small_frame_probe.py, frames/s at sub-batches of 1 / 2 / 4 / 8 / 16 / 32): 256 x 456 - the
 # reference's own video shape, content_size = 256 - 1587 / 2164 / 2431 / 2570 / 2590 / 2579; 512 x 912: 611 / 646 / 670 / 671 / 659 /
 # 651; 1080p: 154 / 153 / 151 / 148 / 146 / 145.  Small frames need company to fill the chip (a 256 x 456 frame is 960 tile items
 # for 512 resident workgroups); large ones lose to the L2-miss traffic that grows faster than the batch.
-AUTO_SUB_BATCH_PIXELS = 2.0e6
+AUTO_SUB_BATCH_PIXELS = 3.0e6
 MAX_AUTO_SUB_BATCH = 32
 
 
@@ -463,8 +463,8 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
     depth_maps      optional sequence of [h0,w0] proximity maps, one per frame -> depth-aware blend (test.py:52-71) with
                     ``depth_offset`` / ``depth_prominence``; otherwise the ``alpha`` blend (test.py:74-81).
     masks           optional sequence of [1|3,hm,wm] masks -> content-mask composite (test.py:222-236).
-    sub_batch       frames per sub-batch; None (default) = chosen from the frame size, about two megapixels per sub-batch
-                    (``auto_sub_batch``: 16 frames of 256 x 456, 4 of 512 x 912, 1 of 1080p - measured optima).
+    sub_batch       frames per sub-batch; None (default) = chosen from the frame size, about three megapixels per sub-batch
+                    (``auto_sub_batch``: 26 frames of 256 x 456, 6 of 512 x 912, 2 of 1200 x 1600, 1 of 1080p - inside the measured optima).
     post            optional ``f(u8_block) -> u8_block`` applied per sub-batch on the owning rank BEFORE the gather
                     (frame-local work such as the INTER_AREA resize, so the gather moves the small frames).
     sink            optional ``f(i, j, u8_block)`` called with every finished sub-batch (frames i..j-1) on the owning rank.
