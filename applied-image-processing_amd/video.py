@@ -81,7 +81,7 @@ def _run(content_dir, style_paths, output_dir, flow_method, alpha, target_resolu
     os.makedirs(output_dir, exist_ok=True)
     names = _frame_files(content_dir)
     rank, world = sh.rank_world(group)
-    dev = engine.device if engine is not None else None
+    dev = engine.device if engine is not None else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
     # Everything that can stop the job is settled BEFORE any rank starts computing, with one status word, so that no rank is
     # ever left waiting in a collective for a peer that has returned or raised: cancellation (the flag is a per-process Event),
     # and the optical-flow provider the rank-0 recurrence will need from the second frame on.
