@@ -40,6 +40,7 @@ Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
+import math
 import os
 import statistics
 import sys
@@ -201,10 +202,34 @@ class MaskStore:
         return self.m[self.f._own(k)]
 
 
+class DepthStore:
+    """Per-frame proximity maps of the video job's depth-aware variant ("a per-frame synthetic depth"): the
+    smooth field of ``synth.smooth_depth`` with frame k's own 5 % noise (seed 6 + k), f32 [h,w] beside the frames (HBM or host)."""
+
+    def __init__(self, frames, h, w, device):
+        self.f = frames
+        yy = np.arange(h, dtype=np.float64)[:, None] / max(h, 1)
+        xx = np.arange(w, dtype=np.float64)[None, :] / max(w, 1)
+        f = (np.sin(2 * math.pi * (1.0 * yy + 0.5 * xx)) + 0.7 * np.sin(2 * math.pi * (0.5 * yy - 1.5 * xx) + 1.0)
+             + 0.5 * np.sin(2 * math.pi * (2.0 * yy + 1.0 * xx) + 2.0) + 0.3 * np.sin(2 * math.pi * (3.0 * xx) + 0.5))
+        f = torch.from_numpy((f - f.min()) / (f.max() - f.min())).to(device)
+        self.m = []
+        for k in range(frames.lo, frames.hi):
+            noise = synth.uniform01_torch(6 + k, h * w, device).reshape(h, w).double()
+            d = ((0.95 * f + 0.05 * noise) * 1000.0).float()
+            self.m.append(d.cpu().numpy() if frames.host else d)
+
+    def __len__(self):
+        return self.f.n
+
+    def __getitem__(self, k):
+        return self.m[self.f._own(k)]
+
+
 class Step:
     """One pass of the hot path on device-resident inputs through the C ABI (see the module docstring)."""
 
-    def __init__(self, device, config=2, first_frame=0, size=None, style_size=512, batch=1, alpha=0.5, engine=None, weights=None):
+    def __init__(self, device, config=2, first_frame=0, size=None, style_size=512, batch=1, alpha=0.5, engine=None, weights=None, depth=False):
         self.config, self.alpha, self.batch, self.device = config, alpha, batch, device
         self.h, self.w = SIZES[config]
         if size:
@@ -218,7 +243,9 @@ class Step:
         self.style = torch.from_numpy(synth.image(4, 1, self.hs, self.ws)).to(device)
         self.hc, self.wc = rt.encoded_size(self.h, self.w)
         self.style_each_step = config in (2, 3)
-        if config == 3:
+        self.depth = None
+        self.depth_offset = 0.15 if config == 3 else 0.30      # run_depth.py:33-40 defaults / the video caller's (video/utils.py:240)
+        if config == 3 or depth:       # config 3, and the depth-aware variant of the video job (--depth)
             self.depth = [torch.from_numpy(synth.smooth_depth(6 + first_frame + i, self.h, self.w)).to(device) for i in range(batch)]
         if config == 5:
             self.mask = (self.content > 0).float()
@@ -288,9 +315,9 @@ class Step:
             ev += [(ev_c[i + 1], ev_c[i + 2]) for i in range(8)]
             self.edge_ev.append(("conv_first_kernel (NCHW image -> 64-ch NHWC)", first_px * (12 + 256), ev_c[0], ev_c[1]))
         c_mean, c_std = T("mean_std_nhwc_partial + finalize (content relu4_1)", feat_bytes, rt.mean_std, cf, True)
-        if self.config == 3:
+        if self.depth is not None:
             p = torch.cat([T("bicubic_minmax + strength_sum + strength_apply (P map)", self.h * self.w * 4 + hc * wc * 12,
-                             rt.strength_map, d, hc, wc, 0.15, 20) for d in self.depth])
+                             rt.strength_map, d, hc, wc, self.depth_offset, 20) for d in self.depth])
             g = T("adain_blend_kernel (P-map blend)", 2 * feat_bytes, rt.blend_pmap, cf, True, c_mean, c_std, s_mean, s_std, p)
         else:
             g = T("adain_blend_kernel (alpha blend)", 2 * feat_bytes, rt.blend_alpha, cf, True, c_mean, c_std, s_mean, s_std, self.alpha)
@@ -406,7 +433,7 @@ def measure_pixel_kernels(device, reps=10):
     return out
 
 
-def cpu_baseline(step, gpu_out, job_frames=None):
+def cpu_baseline(step, gpu_out, job_frames=None, job_depth=None):
     """The oracle on this node's host cores, same workload, bounded sample (about 10-30 s): configs 2 / 3 whole forwards of
     the step's first frame; configs 4 / 5 two frames of the job (per-frame cost is constant)."""
     from oracle import adain_oracle as O
@@ -426,11 +453,22 @@ def cpu_baseline(step, gpu_out, job_frames=None):
         if cfg in (4, 5) and len(frames) < 2:
             frames.append(synth_frame(cfg, step.first_frame + 1, h, w))
 
+    depth = None
+    if job_depth is not None:
+        depth = [torch.as_tensor(d).cpu() for d in job_depth]
+    elif step.depth is not None:
+        depth = [d.cpu() for d in step.depth[:2]]
+        if len(depth) < len(frames):
+            depth.append(torch.from_numpy(synth.smooth_depth(6 + step.first_frame + 1, h, w)))
+
     def forward(i):
         c = frames[i]
         if cfg == 3:
-            return O.style_transfer(vgg_sd, dec_sd, c, s, step.depth[i].cpu(), 1.0, 0.15, 20)
-        out = O.style_transfer_simple(vgg_sd, dec_sd, c, s, step.alpha)
+            return O.style_transfer(vgg_sd, dec_sd, c, s, depth[i], 1.0, step.depth_offset, 20)
+        if depth is not None:
+            out = O.style_transfer(vgg_sd, dec_sd, c, s, depth[i], 1.0, step.depth_offset, 20)
+        else:
+            out = O.style_transfer_simple(vgg_sd, dec_sd, c, s, step.alpha)
         if cfg == 5:
             out = O.mask_composite(c, out, (c[0] > 0))
         return O.quantize_u8(out) if cfg in (4, 5) else out
@@ -461,7 +499,7 @@ def cpu_baseline(step, gpu_out, job_frames=None):
     except Exception:
         model = "unknown"
     what = {2: "full style_transfer_simple forwards", 3: "full depth-aware style_transfer forwards",
-            4: "video-job frames (forward + uint8), per-frame rate", 5: "guide views (forward + mask composite + uint8), per-view rate"}[cfg]
+            4: ("depth-aware " if depth is not None else "") + "video-job frames (forward + uint8), per-frame rate", 5: "guide views (forward + mask composite + uint8), per-view rate"}[cfg]
     return {
         "value": round(h * w / 1e6 / best, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
         "sample": f"{len(times)} {what} of the same workload ({h}x{w} content, {step.hs}x{step.ws} style"
@@ -479,6 +517,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=0, help="override content H = W")
     ap.add_argument("--style-size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 1); with --job: frames per sub-batch (default: chosen by the driver from the frame size, jobs.auto_sub_batch: 1 at 1080p; sub-batches of 1 / 2 / 4 / 8 / 16 measured 319 / 317 / 313 / 307 / 303 Mpixels/s there, while 256 x 456 frames peak at 16)")
+    ap.add_argument("--depth", action="store_true", help="config 4: the depth-aware variant (a synthetic proximity map per frame, use_depth=True of the reference's video caller: offset 0.30, prominence 20)")
     ap.add_argument("--job", action="store_true", help="configs 4 / 5: run the BASELINE job (512 frames / 300 views) strong-scaled over the ranks")
     ap.add_argument("--frames", type=int, default=0, help="--job: frames of the whole job (default 512 / 300)")
     ap.add_argument("--host-frames", action="store_true",
@@ -494,6 +533,8 @@ def parse_args():
     args = ap.parse_args()
     if args.job and args.config not in (4, 5):
         ap.error("--job runs the video job (--config 4) or the guide-view job (--config 5)")
+    if args.depth and args.config != 4:
+        ap.error("--depth is the depth-aware variant of the video job (--config 4); config 3 is depth-aware by itself")
     if args.steps is None:
         args.steps = 3 if args.job else 20
     if args.warmup is None:
@@ -582,9 +623,10 @@ def main_job(args, ctx):
     style_cache = {}
     via_rccl = ctx.use_dist and ctx.transport == "rccl"       # (--rehearse: ranks share a GPU, the gather moves host copies over gloo)
 
-    def make_job(frames, masks, host_result=None):
+    def make_job(frames, masks, host_result=None, depth_maps=None):
         def job():
-            res, info = jobs.stylize_frames_sharded(engine, frames, style, alpha=0.5, masks=masks, sub_batch=args.batch or None, gather=ctx.use_dist,
+            res, info = jobs.stylize_frames_sharded(engine, frames, style, alpha=0.5, masks=masks, depth_maps=depth_maps, depth_offset=0.30,
+                                                    depth_prominence=20, sub_batch=args.batch or None, gather=ctx.use_dist,
                                                     require_transport="rccl" if via_rccl and world > 1 else None, style_cache=style_cache,
                                                     out_hw=(h, w), gather_chunks=args.gather_chunks,
                                                     host_out=host_result)      # the finished frames leave the device behind the kernels
@@ -593,8 +635,9 @@ def main_job(args, ctx):
 
     frames = FrameStore(cfg, n_total, lo, hi, h, w, device, host=False)
     masks = MaskStore(frames) if cfg == 5 else None
+    depths = DepthStore(frames, h, w, device) if args.depth else None
     ctx.warm_transport(world, 1)
-    dt, res, info = jobs.run_timed_jobs(make_job(frames, masks), args.steps, args.warmup, barrier=ctx.barrier)
+    dt, res, info = jobs.run_timed_jobs(make_job(frames, masks, depth_maps=depths), args.steps, args.warmup, barrier=ctx.barrier)
     if rank == 0:
         assert res is not None and res.shape == (n_total, h, w, 3), (None if res is None else res.shape)
     first_u8 = res[:2].clone() if rank == 0 else None
@@ -611,8 +654,9 @@ def main_job(args, ctx):
         del res
         host_frames = FrameStore(cfg, n_total, lo, hi, h, w, device, host=True)
         host_masks = MaskStore(host_frames) if cfg == 5 else None
+        host_depths = DepthStore(host_frames, h, w, device) if args.depth else None
         host_out = torch.empty((n_total, h, w, 3), dtype=torch.uint8).pin_memory() if rank == 0 else None
-        pdt, pres, pinfo = jobs.run_timed_jobs(make_job(host_frames, host_masks, host_out), args.steps, args.warmup, barrier=ctx.barrier)
+        pdt, pres, pinfo = jobs.run_timed_jobs(make_job(host_frames, host_masks, host_out, host_depths), args.steps, args.warmup, barrier=ctx.barrier)
         if rank == 0:
             assert torch.equal(host_out[:2], first_u8.cpu()), "host-resident job differs from the HBM-resident one"
         pcie = {"value": round(n_total * h * w / 1e6 / (pdt / args.steps), 3), "unit": "Mpixels/s", "ms_per_step": round(pdt / args.steps * 1e3, 3),
@@ -625,14 +669,14 @@ def main_job(args, ctx):
     if rank == 0:
         sec_per_job = dt / args.steps
         value = n_total * h * w / 1e6 / sec_per_job
-        what = {4: f"configs[3]: video job, {n_total} frames {h}x{w}", 5: f"configs[4]: 3DGS guide-view job, {n_total} views {h}x{w} with masks"}[cfg]
+        what = {4: f"configs[3]: video job, {n_total} frames {h}x{w}" + (", depth-aware (a proximity map per frame, offset 0.30, prominence 20)" if args.depth else ""), 5: f"configs[4]: 3DGS guide-view job, {n_total} views {h}x{w} with masks"}[cfg]
         shard = sh.shard_counts(n_total, world)
         workload = (f"{what}, one {hs}x{ws} style (statistics cached per rank), sub-batches of {sub}{' (automatic)' if not args.batch else ''}, decoded uint8 frames resident in HBM, "
                     f"{'mask composite + ' if cfg == 5 else ''}uint8 out; a step = the whole job")
         parallelism = (f"frame sharding x{world}: contiguous blocks {shard if world > 1 else ''} per rank, replicated weights and style statistics, "
                        f"one status word + ONE gather of the uint8 frames to rank 0 per job" if ctx.use_dist else "single GPU, no collective")
         result = base_result(args, ctx, value, sec_per_job * 1e3, workload, parallelism, "strong")
-        step = Step(device, config=cfg, first_frame=0, style_size=args.style_size, batch=sub, engine=engine, weights=weights)
+        step = Step(device, config=cfg, first_frame=0, style_size=args.style_size, batch=sub, engine=engine, weights=weights, depth=args.depth)
         roof, layers, secondary = measure_roofline(step, 5)
         result["roofline"] = roof
         result["secondary"] = secondary
@@ -651,7 +695,8 @@ def main_job(args, ctx):
         if world == 1 and not args.no_cpu:
             step.run()
             torch.cuda.synchronize()
-            cb, psnr, rel = cpu_baseline(step, first_u8, job_frames=[frames[k] for k in range(min(2, n_total))])
+            cb, psnr, rel = cpu_baseline(step, first_u8, job_frames=[frames[k] for k in range(min(2, n_total))],
+                                          job_depth=[depths[k] for k in range(min(2, n_total))] if depths is not None else None)
             result["cpu_baseline"] = cb
             result["psnr_db_vs_cpu"] = round(psnr, 2) if psnr != float("inf") else "inf"
             result["rel_l2_vs_cpu"] = float(f"{rel:.3e}")
@@ -670,7 +715,7 @@ def main():
     world, rank, device, use_dist, transport, shared_gpu = ctx.world, ctx.rank, ctx.device, ctx.use_dist, ctx.transport, ctx.shared_gpu
     barrier = ctx.barrier
 
-    step = Step(device, config=args.config, first_frame=rank * args.batch, size=args.size, style_size=args.style_size, batch=args.batch)
+    step = Step(device, config=args.config, first_frame=rank * args.batch, size=args.size, style_size=args.style_size, batch=args.batch, depth=args.depth)
     h, w, hs, ws = step.h, step.w, step.hs, step.ws
     n_job = world * args.batch                        # frames of one step's job over all ranks
 
@@ -722,7 +767,8 @@ def main():
         ms = dt / args.steps * 1e3
         value = n_job * h * w / 1e6 / (dt / args.steps)
         roof, layers, secondary = measure_roofline(step, 5)
-        result = base_result(args, ctx, value, ms, WORKLOADS[args.config].format(h=h, w=w, hs=hs, ws=ws, b=args.batch),
+        result = base_result(args, ctx, value, ms, WORKLOADS[args.config].format(h=h, w=w, hs=hs, ws=ws, b=args.batch)
+                             + ("; depth-aware variant (a proximity map per frame, offset 0.30, prominence 20)" if args.depth else ""),
                              f"frame sharding x{world}: contiguous frame blocks per rank, replicated weights and style "
                              "statistics, one gather of the uint8 frames to rank 0 per step" if use_dist else "single GPU, no collective", "weak")
         result["roofline"] = roof

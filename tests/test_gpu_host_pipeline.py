@@ -169,6 +169,27 @@ def test_bench_frame_store_is_the_host_generator(rt):
     assert (v[bg] == 0).all() and 0.2 < bg.mean() < 0.4
 
 
+def test_bench_depth_store_is_the_host_generator_and_job_equals_direct_call(rt, engine):
+    """bench.py --config 4 --depth: the per-frame proximity maps built on the GPU are ``synth.smooth_depth``'s bits, and the job
+    driver's depth-aware frames equal direct depth-aware engine calls ("a per-frame synthetic depth")."""
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    import bench
+    import applied_image_processing_amd.jobs as jobs
+
+    h, w, n = 64, 96, 5
+    frames = bench.FrameStore(4, n, 0, n, h, w, torch.device("cuda", 0))
+    depths = bench.DepthStore(frames, h, w, torch.device("cuda", 0))
+    for k in (0, 3):
+        assert np.array_equal(depths[k].cpu().numpy(), synth.smooth_depth(6 + k, h, w))
+    style = torch.from_numpy(synth.image(4, 1, 64, 64)).cuda()
+    u8, _ = jobs.stylize_frames_sharded(engine, frames, style, depth_maps=depths, depth_offset=0.30, depth_prominence=20, sub_batch=2, gather=False)
+    engine.set_style(style)
+    for k in range(n):
+        direct = engine.to_u8(engine.stylize_depth(frames[k][None], [depths[k]], 0.30, 20))
+        assert torch.equal(u8[k], direct[0]), k
+
+
 def test_jobs_random_shapes_host_feeder_vs_direct_engine_calls(rt, engine):
     """Random frame counts, sizes (both tile geometries, ragged), sub-batch sizes, feeder depths, with / without masks and proximity
     maps: the job driver fed from pageable host uint8 frames must give exactly the uint8 frames of direct engine calls on
