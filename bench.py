@@ -82,7 +82,7 @@ CONV_KERNEL = ("conv3x3_mfma_kernel / conv3x3_persist_kernel" if not WINOGRAD el
                "conv3x3_wino4_kernel (Winograd F(4,3) x F(2,3))" if WINO_FORM == 5 else
                "conv3x3_wino2_kernel + conv3x3_wino3_kernel (Winograd F(2x2,3x3))")
 WORKLOADS = {
-    2: "configs[1]: {h}x{w} AdaIN forward (style_transfer_simple), batch={b} per GPU, style {hs}x{ws} re-encoded every step, alpha=0.5",
+    2: "configs[1]: {h}x{w} AdaIN forward (style_transfer_simple), batch={b} per GPU, style {hs}x{ws} re-encoded every step, alpha={alpha}",
     3: "configs[2]: {h}x{w} depth-aware AdaIN (style_transfer, proximity-map blend), batch={b} per GPU, style {hs}x{ws} re-encoded every step",
     4: "configs[3]: one sub-batch of the video job per step, frames {h}x{w}, {b} frames per GPU per step, one {hs}x{ws} style (statistics cached per rank), uint8 out",
     5: "configs[4]: one sub-batch of the 3DGS guide-view job per step, views {h}x{w} with masks, {b} views per GPU per step, one {hs}x{ws} style, mask composite + uint8 out",
@@ -515,7 +515,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 1 job with --job)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[] index + 1 (default 2 = configs[1])")
     ap.add_argument("--size", type=int, default=0, help="override content H = W")
-    ap.add_argument("--style-size", type=int, default=512)
+    ap.add_argument("--style-size", type=int, default=512, help="style H = W (512 = the API default style_size; SURVEY 8(d) also names the 1024 variant of config 2)")
+    ap.add_argument("--alpha", type=float, default=0.5, help="configs 2 / 4 / 5: content-style trade-off of the alpha blend (default 0.5; SURVEY 8(d) also names 1.0)")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 1); with --job: frames per sub-batch (default: chosen by the driver from the frame size, jobs.auto_sub_batch: 1 at 1080p; sub-batches of 1 / 2 / 4 / 8 / 16 measured 319 / 317 / 313 / 307 / 303 Mpixels/s there, while 256 x 456 frames peak at 16)")
     ap.add_argument("--depth", action="store_true", help="config 4: the depth-aware variant (a synthetic proximity map per frame, use_depth=True of the reference's video caller: offset 0.30, prominence 20)")
     ap.add_argument("--job", action="store_true", help="configs 4 / 5: run the BASELINE job (512 frames / 300 views) strong-scaled over the ranks")
@@ -625,7 +626,7 @@ def main_job(args, ctx):
 
     def make_job(frames, masks, host_result=None, depth_maps=None):
         def job():
-            res, info = jobs.stylize_frames_sharded(engine, frames, style, alpha=0.5, masks=masks, depth_maps=depth_maps, depth_offset=0.30,
+            res, info = jobs.stylize_frames_sharded(engine, frames, style, alpha=args.alpha, masks=masks, depth_maps=depth_maps, depth_offset=0.30,
                                                     depth_prominence=20, sub_batch=args.batch or None, gather=ctx.use_dist,
                                                     require_transport="rccl" if via_rccl and world > 1 else None, style_cache=style_cache,
                                                     out_hw=(h, w), gather_chunks=args.gather_chunks,
@@ -676,7 +677,7 @@ def main_job(args, ctx):
         parallelism = (f"frame sharding x{world}: contiguous blocks {shard if world > 1 else ''} per rank, replicated weights and style statistics, "
                        f"one status word + ONE gather of the uint8 frames to rank 0 per job" if ctx.use_dist else "single GPU, no collective")
         result = base_result(args, ctx, value, sec_per_job * 1e3, workload, parallelism, "strong")
-        step = Step(device, config=cfg, first_frame=0, style_size=args.style_size, batch=sub, engine=engine, weights=weights, depth=args.depth)
+        step = Step(device, config=cfg, first_frame=0, style_size=args.style_size, batch=sub, engine=engine, weights=weights, depth=args.depth, alpha=args.alpha)
         roof, layers, secondary = measure_roofline(step, 5)
         result["roofline"] = roof
         result["secondary"] = secondary
@@ -715,7 +716,8 @@ def main():
     world, rank, device, use_dist, transport, shared_gpu = ctx.world, ctx.rank, ctx.device, ctx.use_dist, ctx.transport, ctx.shared_gpu
     barrier = ctx.barrier
 
-    step = Step(device, config=args.config, first_frame=rank * args.batch, size=args.size, style_size=args.style_size, batch=args.batch, depth=args.depth)
+    step = Step(device, config=args.config, first_frame=rank * args.batch, size=args.size, style_size=args.style_size, batch=args.batch, depth=args.depth,
+                alpha=args.alpha)
     h, w, hs, ws = step.h, step.w, step.hs, step.ws
     n_job = world * args.batch                        # frames of one step's job over all ranks
 
@@ -767,7 +769,7 @@ def main():
         ms = dt / args.steps * 1e3
         value = n_job * h * w / 1e6 / (dt / args.steps)
         roof, layers, secondary = measure_roofline(step, 5)
-        result = base_result(args, ctx, value, ms, WORKLOADS[args.config].format(h=h, w=w, hs=hs, ws=ws, b=args.batch)
+        result = base_result(args, ctx, value, ms, WORKLOADS[args.config].format(h=h, w=w, hs=hs, ws=ws, b=args.batch, alpha=args.alpha)
                              + ("; depth-aware variant (a proximity map per frame, offset 0.30, prominence 20)" if args.depth else ""),
                              f"frame sharding x{world}: contiguous frame blocks per rank, replicated weights and style "
                              "statistics, one gather of the uint8 frames to rank 0 per step" if use_dist else "single GPU, no collective", "weak")
