@@ -589,6 +589,11 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
         err = e
     finally:
         feeder.close()
+    if err is not None:                    # a failed job: its kernels may still read the feeder's slot buffers - let them finish before
+        try:                               # the buffers go back to the allocator on the way out
+            engine.synchronize()
+        except Exception:
+            pass
     info["h2d_bytes"] = feeder.h2d_bytes
     info["fetch_s"] = feeder.fetch_s
     info["feeder"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in feeder.stats.items()}
