@@ -766,6 +766,12 @@ static long long persistent_grid() {
     const int cus = device_cu_count();
     if (cus <= 0) return 0;
     long long pgrid = 2LL * cus;
+#ifdef ADAIN_DIAG
+    // timing experiment (tools/probes/one_wave_probe.py): ADAIN_W4_WGS=1 leaves one workgroup per CU = ONE wave per SIMD, nothing
+    // beside a wave's stalls and a tile's epilogue - what a split with more accumulators per wave would have to live with
+    static const int wgs = tune_env("ADAIN_W4_WGS", 2);
+    pgrid = (long long)(wgs == 1 ? 1 : 2) * cus;
+#endif
     return pgrid - pgrid % 8;
 }
 
