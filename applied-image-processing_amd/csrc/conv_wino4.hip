@@ -294,8 +294,9 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
 #pragma unroll
         for (int k = 0; k < W4_RITEMS; ++k) rawreg[k] = buf_load4(src, roff[k], tbase + soff);
     };
-    // LDS address (in floats) of staging item k of this thread: pixel (t >> 2) + 64 k of the halo, quad t & 3; depends on the
-    // thread only, computed once
+    // LDS address (in BYTES from the start of a halo buffer) of staging item k of this thread: pixel (t >> 2) + 64 k of the halo,
+    // quad t & 3; depends on the thread only, computed once.  Bytes, so that a store into a buffer whose place is known at compile
+    // time is the register + an immediate offset (the persistent form's stage loop: no address arithmetic at all).
     int sa[W4_RITEMS];
     {
         const int t = tid;
@@ -303,14 +304,14 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         for (int k = 0; k < W4_RITEMS; ++k) {
             const int hp = (t >> 2) + 64 * k, q = t & 3;
             const int hy = hp / W4_HALO_W, hx = hp - hy * W4_HALO_W;
-            sa[k] = hp < W4_HALO ? (hx & 1) * W4_PLANE + hy * W4_PROW + (hx >> 1) * W4_RSTR + q * 4
-                                 : W4_TAIL + (hp - W4_HALO) * W4_RSTR + q * 4;
+            sa[k] = 4 * (hp < W4_HALO ? (hx & 1) * W4_PLANE + hy * W4_PROW + (hx >> 1) * W4_RSTR + q * 4
+                                      : W4_TAIL + (hp - W4_HALO) * W4_RSTR + q * 4);
             asm volatile("" : "+v"(sa[k]));      // held in a register: left alone the compiler recomputes it (8 vector
         }                                        // instructions per item and stage, and every one of them costs matrix-pipe time)
     }
     auto raw_store = [&](float* buf) {
 #pragma unroll
-        for (int k = 0; k < W4_RITEMS; ++k) *(f32x4*)(buf + sa[k]) = rawreg[k];
+        for (int k = 0; k < W4_RITEMS; ++k) *(f32x4*)((char*)buf + sa[k]) = rawreg[k];
     };
 
     // ---- weights: one b128 fragment per step (row position r), ring slot = r, loaded 5 steps ahead ---------------------------
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 }
                 // ---- halo store of the stage loaded one stage ago ----
                 if constexpr (st && DIAG != 8 && DIAG != 11) {
-                    if constexpr (h >= 17 && h <= 22) *(f32x4*)(store_to + sa[h - 17]) = rawreg[h - 17];
+                    if constexpr (h >= 17 && h <= 22) *(f32x4*)((char*)store_to + sa[h - 17]) = rawreg[h - 17];
                 }
                 if constexpr (st && DIAG == 11) {      // timing-only: halo loads kept alive without the LDS stores
                     if constexpr (h >= 17 && h <= 22) asm volatile("" ::"v"(rawreg[h - 17]));
@@ -639,29 +640,39 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                     __builtin_amdgcn_s_setprio(0);
                 }
                 ++ntile;
-                // the halo loads run two stages ahead: once the current tile's last stage has been requested (in iteration
-                // nst-3, or by the tile's entry code when nst == 2) the offsets switch to the next tile (loop tail, so that no
-                // branch splits the two chunks of a stage)
+                // The halo loads run two stages ahead, and the staging offsets (six vector registers, the scalar tile base, the source
+                // descriptor) switch to the next tile at ONE straight-line point: behind the stage loop, in front of the tile's last two
+                // chunks, whose first then requests the next tile's first stage (it still has that chunk's tail, a whole chunk and the
+                // epilogue's exchange to arrive).  Round 2 switched inside the loop ("if (s == nst - 3)", two more call sites for
+                // nst = 2 / 3): the registers then were loop-carried values redefined on one path, and the compiler kept two copies of
+                // them, 12 v_mov per stage (3 % of the stage's vector instructions - which cost matrix-pipe time here) besides three
+                // inlined copies of the offset code.  The price: the stage that has nothing left to request re-requests the tile's
+                // last stage (six loads per thread and tile that hit in L1 / L2 and are never stored).
                 auto next_halo = [&]() {
                     halo_offsets(ntx0, nty0, m.s[nseg].H, m.s[nseg].W, m.s[nseg].Ws, nseg);
                     src = src_of(m.s[nseg].in, m.s[nseg].Hs, m.s[nseg].Ws, nimg, nty0);
                 };
-                if (nst == 2) next_halo();
                 {   // stage 0, peeled: its first chunk starts the tile's accumulators (FIRST)
                     chunk(Rs + 8, T, T, F, 0, Rs + W4_RBUF, wso + 6144, P0, T);
                     __syncthreads();
-                    chunk(Rs + W4_RBUF, T, F, T, nst == 2 ? 0 : 2 * W4_KR * 4, nullptr, wso + 6144, P1, F);
-                    if (nst == 3) next_halo();
+                    chunk(Rs + W4_RBUF, T, F, T, min(2, nst - 1) * W4_KR * 4, nullptr, wso + 6144, P1, F);
                 }
-                for (int s = 1; s + 1 < nst; ++s) {
-                    const float* cur = Rs + (s & 1) * W4_RBUF;
-                    float* nxt = Rs + ((s + 1) & 1) * W4_RBUF;
-                    chunk(cur + 8, T, T, F, 0, nxt, wso + 6144, P0, F);
+                // stages 1 .. nst-2 in pairs (odd stage: reads buffer 1, fills buffer 0; even stage: the reverse), so that every LDS
+                // address of the loop is a register + an immediate: with the buffer a run-time value the loop spent 8 vector
+                // instructions per stage on `base + offset` (of 152; every one costs matrix-pipe time).  cin a multiple of 32 gives
+                // whole pairs; otherwise the last pair is its first half.
+                for (int s = 1; s + 1 < nst; s += 2) {
+                    chunk(Rs + W4_RBUF + 8, T, T, F, 0, Rs, wso + 6144, P0, F);
                     __syncthreads();
-                    chunk(nxt, T, F, T, s == nst - 2 ? 0 : (s + 2) * W4_KR * 4, nullptr, wso + 6144, P1, F);
-                    if (s == nst - 3) next_halo();
+                    chunk(Rs, T, F, T, min(s + 2, nst - 1) * W4_KR * 4, nullptr, wso + 6144, P1, F);
+                    if (s + 2 < nst) {
+                        chunk(Rs + 8, T, T, F, 0, Rs + W4_RBUF, wso + 6144, P0, F);
+                        __syncthreads();
+                        chunk(Rs + W4_RBUF, T, F, T, min(s + 3, nst - 1) * W4_KR * 4, nullptr, wso + 6144, P1, F);
+                    }
                 }
-                chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, wso + 6144, P0, F);
+                next_halo();
+                chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, T, 0, nullptr, wso + 6144, P0, F);      // + the next tile's first halo stage
                 chunk(Rs, F, F, F, 0, nullptr, wso_next, P1, F);      // the ring's look-ahead continues in the next tile's weights
                 wso = wso_next;
                 if constexpr (DIAG == 4) tpx[1] = __builtin_amdgcn_s_memtime();
