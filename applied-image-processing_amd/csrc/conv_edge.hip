@@ -184,7 +184,15 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restri
                     const int ch = 32 * c + 8 * q + 4 * lh;
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[c][m][4 * q + e], 0.f);      // the bias came in through K
+                    // ReLU as ONE instruction: max over the BIT PATTERNS as signed integers (negative floats, -0 and negative NaNs are
+                    // negative integers -> +0; everything else unchanged: fmaxf(x, 0) for every x).  fmaxf itself costs two v_max
+                    // here - accumulators straight out of an MFMA get a canonicalising v_max(x, x) first - and every vector
+                    // instruction takes matrix-pipe time on this chip.  (The bias came in through K.)
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = acc[c][m][4 * q + e];
+                        const int xi = __float_as_int(x);
+                        v[e] = __int_as_float(xi > 0 ? xi : 0);
+                    }
                     *(f32x4*)(st + li * CF_OSTR + ch) = v;
                 }
             // the row buffer is private to the wave and LDS operations of one wave complete in order: no barrier
