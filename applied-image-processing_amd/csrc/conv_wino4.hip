@@ -596,12 +596,17 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         if constexpr (DIAG == 3) phase[1] = __builtin_amdgcn_s_memrealtime();
 
         if constexpr (!PERSIST) {
-            for (int s = 0; s + 1 < nst; ++s) {
-                const float* cur = Rs + (s & 1) * W4_RBUF;
-                float* nxt = Rs + ((s + 1) & 1) * W4_RBUF;
-                chunk(cur + 8, T, T, F, 0, nxt, wso + 6144, P0, F);                // channels 0..7; prepares 8..15; writes the next stage's halo
+            // stages in pairs (even stage: reads buffer 0, fills buffer 1; odd stage: the reverse): every LDS address of the loop is a
+            // register + an immediate (see the persistent form); the last pair is its first half when nst is even
+            for (int s = 0; s + 1 < nst; s += 2) {
+                chunk(Rs + 8, T, T, F, 0, Rs + W4_RBUF, wso + 6144, P0, F);        // channels 0..7; prepares 8..15; writes the next stage's halo
                 if constexpr (DIAG != 7) __syncthreads();
-                chunk(nxt, T, F, T, (s + 2) * W4_KR * 4, nullptr, wso + 6144, P1, F);      // channels 8..15; prepares the next stage; loads two stages ahead
+                chunk(Rs + W4_RBUF, T, F, T, (s + 2) * W4_KR * 4, nullptr, wso + 6144, P1, F);      // channels 8..15; prepares the next stage; loads two stages ahead
+                if (s + 2 < nst) {
+                    chunk(Rs + W4_RBUF + 8, T, T, F, 0, Rs, wso + 6144, P0, F);
+                    if constexpr (DIAG != 7) __syncthreads();
+                    chunk(Rs, T, F, T, (s + 3) * W4_KR * 4, nullptr, wso + 6144, P1, F);
+                }
             }
             chunk(Rs + ((nst - 1) & 1) * W4_RBUF + 8, T, F, F, 0, nullptr, wso + 6144, P0, F);
             chunk(Rs, F, F, F, 0, nullptr, wso + 6144, P1, F);
