@@ -84,9 +84,14 @@ def probe(cin, cout, h, relu_data=True):
             last = t
             cur += dl
         tot[0] += t_end - last
+    # how uneven are the workgroups' walks?  (a workgroup's duration = its last stamp - its first; every workgroup starts with the
+    # launch, so the kernel lasts as long as the slowest walk: max / mean - 1 is what a perfect tail balance could win)
+    dur = (st0[:, -1, 7] - st0[:, 0, 0])
+    print(f"   workgroup walks ({per} tiles): mean {dur.mean():.0f}  p50 {dur.median():.0f}  p90 {dur.quantile(0.9):.0f}  max {dur.max():.0f} cycles; "
+          f"max / mean - 1 = {100 * (dur.max() / dur.mean() - 1):.1f} %, p90 / mean - 1 = {100 * (dur.quantile(0.9) / dur.mean() - 1):.1f} %")
     n = sum(tot)
     print(f"   {len(pairs)} CUs with two workgroups: time with 0 / 1 / 2 of them inside a main loop: {tot[0] / n:.3f} / {tot[1] / n:.3f} / {tot[2] / n:.3f}")
 
 
-for shape in ((64, 64, 1024), (64, 128, 512), (128, 128, 512), (256, 256, 256)):
+for shape in ((64, 64, 1024), (64, 128, 512), (128, 128, 512), (256, 256, 256), (256, 256, 512)):
     probe(*shape)
