@@ -49,6 +49,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
+# this pool's host driver only supports dmabuf IPC: without this RCCL's communicator set-up between processes fails with
+# `hipIpcGetMemHandle: invalid argument`.  The launch environment exports it; kept here for a bare shell (it must be set before the
+# first HIP call of the process, i.e. before anything touches the GPU)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
