@@ -24,6 +24,11 @@ class AdaINEngine:
     def synchronize(self):
         torch.cuda.synchronize(self.device)
 
+    @staticmethod
+    def abi_calls():
+        """C-ABI compute calls this process has made so far (the job drivers report the difference per job)."""
+        return rt.ABI_CALLS[0]
+
     def mark(self):
         """A time stamp on the current stream (a HIP event); ``elapsed(a, b)`` gives the seconds between two of them once the
         work in between has finished.  The job drivers time their phases with these instead of synchronising per phase."""

@@ -279,10 +279,22 @@ class FrameFeeder:
                         self.h2d_done[s].synchronize()                   # the slot's previous uploads have left its pinned buffers
                     t3 = time.perf_counter()
                     self.stats["wait_h2d_s"] += t3 - t2
+                    # device tensors handed over by the stores (a mask or depth map computed lazily in __getitem__, a frame
+                    # made on the GPU) were produced on the fetching threads' current stream, not on the copy stream: whatever
+                    # reads them below - and the consumer, through `ready` - is ordered behind an event recorded there now
+                    on_device = ((isinstance(items, torch.Tensor) and items.is_cuda) or (isinstance(items, list) and items and items[0].is_cuda)
+                                 or any(t.is_cuda for t in (depth or [])) or any(t.is_cuda for t in (mask or [])))
+                    fetched = None
+                    if on_device:
+                        fetched = torch.cuda.Event()
+                        fetched.record(torch.cuda.current_stream(self.device))
                     with torch.cuda.stream(self.copy_stream):
                         if self.consumed[s] is not None:
                             self.copy_stream.wait_event(self.consumed[s])      # the kernels that read this slot have finished
                         staged = False
+                        if fetched is not None:
+                            self.copy_stream.wait_event(fetched)
+                            staged = True                                    # `ready` carries the ordering on to the consumer
                         if isinstance(items, torch.Tensor):              # a ready block (device-resident store)
                             content = items
                         elif items[0].is_cuda:
@@ -382,14 +394,28 @@ class FileSink:
     stream into a pinned buffer, a worker thread waits for it and encodes / saves the files (PIL), so the next sub-batch's
     kernels are already running.  ``close()`` waits for every file and re-raises the first error."""
 
-    def __init__(self, device, workers=4):
+    def __init__(self, device, workers=4, max_in_flight=None):
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
         self.pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="adain-file-sink")
         self.futures = []
         self.d2h_bytes = 0
+        # back-pressure: at most `max_in_flight` blocks (default 2 per writer) sit in pinned memory waiting for their encoder;
+        # write() blocks when the writers fall behind instead of pinning the whole job.  The pinned buffers are reused.
+        self.max_in_flight = max(1, int(max_in_flight if max_in_flight is not None else 2 * workers))
+        self.slots = threading.Semaphore(self.max_in_flight)
+        self.spare = {}                    # block shape -> idle pinned buffers
+        self.spare_lock = threading.Lock()
+        self.wait_s = 0.0                  # time write() spent blocked on the writers
         if self.cuda:
             self.stream = torch.cuda.Stream(self.device)
+
+    def _pinned(self, shape):
+        with self.spare_lock:
+            idle = self.spare.get(shape)
+            if idle:
+                return idle.pop()
+        return torch.empty(shape, dtype=torch.uint8, pin_memory=True)
 
     @staticmethod
     def _save(arr, path):
@@ -399,13 +425,17 @@ class FileSink:
 
     def write(self, u8_block, paths):
         """u8_block [k,h,w,c] on the engine's device (finished on the current stream); paths: k file paths."""
+        t0 = time.perf_counter()
+        self.slots.acquire()
+        self.wait_s += time.perf_counter() - t0
+        shape = tuple(u8_block.shape)
         if not self.cuda:
             host, done = u8_block, None
         else:
             cur = torch.cuda.current_stream(self.device)
             ready = torch.cuda.Event()
             ready.record(cur)
-            host = torch.empty(u8_block.shape, dtype=torch.uint8, pin_memory=True)
+            host = self._pinned(shape)
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ready)
                 host.copy_(u8_block, non_blocking=True)
@@ -415,11 +445,17 @@ class FileSink:
             self.d2h_bytes += u8_block.numel()
 
         def job():
-            if done is not None:
-                done.synchronize()
-            arr = host.numpy()
-            for k, p in enumerate(paths):
-                self._save(arr[k], p)
+            try:
+                if done is not None:
+                    done.synchronize()
+                arr = host.numpy()
+                for k, p in enumerate(paths):
+                    self._save(arr[k], p)
+            finally:
+                if done is not None:
+                    with self.spare_lock:
+                        self.spare.setdefault(shape, []).append(host)
+                self.slots.release()
 
         self.futures.append(self.pool.submit(job))
 
@@ -472,8 +508,11 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
     out_hw          (H, W) of a finished frame, if the caller knows it: lets ``agree=False`` jobs and chunked gathers run with
                     ranks whose block is empty.
     gather_chunks   1: ONE gather when every rank has finished (after the status word: an error anywhere raises everywhere).
-                    k > 1: the block is gathered in k pieces, each issued asynchronously as soon as it is finished so that it
-                    overlaps the rest of the compute (status word at the end only).
+                    k > 1 (needs ``out_hw``; without it the job runs as k = 1): the block is gathered in k pieces, pieces 0 .. k-2
+                    issued asynchronously as soon as they are finished so that they overlap the rest of the compute, then the
+                    status word, then the last piece.  Every rank issues every piece whatever happens to its block - a rank that
+                    fails (or whose frames are not ``out_hw``) sends zero-filled pieces - so the collective sequence is the same
+                    on every rank and the status word still raises everywhere.
     host_out        a (pinned) uint8 host tensor [n,H,W,3]: finished frames are also copied into it, asynchronously on a copy
                     stream as they become available — per sub-batch on a single rank (or with ``gather=False``: every rank fills
                     the rows of its own block), per gathered piece on ``dst`` otherwise — and are all there when the call returns.
@@ -493,18 +532,25 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
     gathering = gather and world > 1
     transport = None
     chunks = max(1, int(gather_chunks)) if gathering else 1
+    if chunks > 1 and out_hw is None:
+        # Pieces are issued inside the frame loop, BEFORE the status word: a rank that fails must still take part in every one of
+        # them (with zero-filled blocks), so it has to know what a finished frame looks like without having finished one.  Without
+        # out_hw the job falls back to the single post-agreement gather - the same decision on every rank (arguments only).
+        chunks = 1
     if gathering:
         transport = sh.device_transport(torch.empty(0, dtype=torch.uint8, device=dev), group)
         if require_transport and transport != require_transport:
             raise RuntimeError(f"final gather would run over {transport!r}, not {require_transport!r}")
-        if (chunks > 1 or not agree) and n < world and out_hw is None:        # the same decision on every rank
-            raise ValueError("a job with fewer frames than ranks needs out_hw for chunked or unagreed gathers")
+        if not agree and n < world and out_hw is None:        # the same decision on every rank
+            raise ValueError("a job with fewer frames than ranks needs out_hw for unagreed gathers")
     counts = sh.shard_counts(n, world)
     # chunk c of rank r = frames [lo_r + a, lo_r + b) with (a, b) = chunk_bounds(counts[r], chunks)[c]
     my_chunks = sh.chunk_bounds(hi - lo, chunks)
 
     info = {"rank": rank, "world": world, "shard": (lo, hi), "transport": transport, "gathers": 0}
     t_host0 = time.perf_counter()
+    cpu0_thread, cpu0_proc = time.thread_time(), time.process_time()
+    abi0 = getattr(engine, "abi_calls", lambda: 0)()
     m0 = _mark(engine)
     blocks, shapes = [], set()             # finished sub-batches (i, j, u8) of this rank, their frame shapes
     pending, landed = [], []               # chunked gather: (chunk, counts, finish closure) in flight; (first frame, block) arrived on dst
@@ -517,14 +563,16 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
     def chunk_ready(c, done_upto):
         return lo + my_chunks[c][1] <= done_upto
 
-    def issue_chunk(c):
+    def issue_chunk(c, zeros=False):
+        """Piece c of this rank's block joins the gather; ``zeros``: this rank has failed - it still takes part, with a zero-filled
+        block of the agreed geometry, so that its peers (already inside the collective) are not left waiting; the status word
+        after the last in-loop piece then raises on every rank."""
         a, b = my_chunks[c]
-        part = [u8 for (i, j, u8) in blocks if lo + a <= i and j <= lo + b]
+        part = [] if zeros else [u8 for (i, j, u8) in blocks if lo + a <= i and j <= lo + b]
         if part:
             local_c = torch.cat(part) if len(part) > 1 else part[0]
         else:
-            geom = tuple(out_hw) + (3,) if out_hw is not None else tuple(blocks[0][2].shape[1:])
-            local_c = torch.empty((0,) + geom, dtype=torch.uint8, device=dev)
+            local_c = torch.zeros((b - a if zeros else 0,) + tuple(out_hw) + (3,), dtype=torch.uint8, device=dev)
         cnts = [sh.chunk_bounds(cr, chunks)[c][1] - sh.chunk_bounds(cr, chunks)[c][0] for cr in counts]
         info["gathers"] += 1
         land_pending()                     # the previous piece has long arrived: hand it on before queueing the next
@@ -580,8 +628,8 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
             if gather or sink is None:
                 blocks.append((i, j, u8))
             if chunks > 1:
-                if len(shapes) > 1:
-                    raise ValueError("stylize_frames_sharded: the gather needs one frame size over the whole job")
+                if tuple(u8.shape[1:3]) != tuple(out_hw):
+                    raise ValueError(f"stylize_frames_sharded: out_hw {tuple(out_hw)} but a finished frame is {tuple(u8.shape[1:3])}")
                 while next_chunk < chunks - 1 and chunk_ready(next_chunk, j):
                     issue_chunk(next_chunk)
                     next_chunk += 1
@@ -594,11 +642,26 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
             engine.synchronize()
         except Exception:
             pass
+    if chunks > 1:
+        # every rank issues every in-loop piece, whatever happened to its block: the collective sequence stays identical
+        # (pieces 0 .. k-2, status word, last piece); a failed rank sends zeros and the status word raises everywhere
+        try:
+            while next_chunk < chunks - 1:
+                issue_chunk(next_chunk, zeros=err is not None)
+                next_chunk += 1
+        except Exception as e:
+            err = err or e
     info["h2d_bytes"] = feeder.h2d_bytes
     info["fetch_s"] = feeder.fetch_s
     info["feeder"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in feeder.stats.items()}
     m1 = _mark(engine)
-    info["enqueue_s"] = time.perf_counter() - t_host0      # host time to fetch, upload and launch the whole block
+    info["enqueue_s"] = time.perf_counter() - t_host0      # host WALL time to fetch, upload and launch the whole block (includes
+                                                           # time blocked on a full HIP queue or an empty feeder queue)
+    # CPU time, which is what eight ranks sharing one host compete for: of the launching thread alone (kernel launches through
+    # the C ABI, tensor bookkeeping) and of the whole process (+ feeder, fetch pool, sink writers, the HIP runtime's own threads)
+    info["host_cpu_s"] = time.thread_time() - cpu0_thread
+    info["process_cpu_s"] = time.process_time() - cpu0_proc
+    info["abi_calls"] = getattr(engine, "abi_calls", lambda: 0)() - abi0
 
     def finish_times(m2=None):
         if copier is not None:
@@ -627,8 +690,19 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
 
     # ---- the job's status word, then its gather ------------------------------------------------------------------------------------
     geom = next(iter(shapes)) if len(shapes) == 1 else None
+    def drop_pending():
+        """An abandoned chunked job: the pieces already issued are complete collectives (every rank took part) - wait for them
+        so that nothing of this job is left in flight on the communicator, and drop the data."""
+        while pending:
+            try:
+                pending.pop(0)[2]()
+            except Exception:
+                pass
+
     if agree:
         ok, geom_all, uniform = sh.agree_geometry(err is None, shapes, group, dev)
+        if err is not None or not ok:
+            drop_pending()
         if err is not None:
             raise err
         if not ok:
@@ -640,6 +714,7 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
         geom = geom_all
     else:
         if err is not None:
+            drop_pending()
             raise err
         if len(shapes) > 1:
             raise ValueError("stylize_frames_sharded: the gather needs one frame size over the whole job")
@@ -658,8 +733,6 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
         if copier is not None and rank == dst:
             copier.copy(host_out, out)
     else:
-        if out_hw is None and not blocks:
-            out_hw = tuple(geom[:2])
         while next_chunk < chunks:
             issue_chunk(next_chunk)
             next_chunk += 1
@@ -794,3 +867,100 @@ def run_timed_jobs(job, steps, warmup, *, barrier, group=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         dt = float(t.item())
     return dt, res, info
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# timed per-step loop (bench.py's default mode with more than one rank; driven on CPU by tests/test_distributed_gloo.py)
+# ---------------------------------------------------------------------------------------------------------------------------------
+GATHER_MODES = ("end", "overlap")
+MAX_END_GATHER_BYTES = 64 << 30        # what rank 0 may be asked to hold for one end-of-region gather
+
+
+def run_timed_steps(step, steps, warmup, *, barrier, block_shape, device, mode="end", gather=True, group=None, dst=0,
+                    mark=None, elapsed=None):
+    """bench.py's contract around single steps: ``warmup`` untimed steps, ``barrier()``, EXACTLY ``steps`` steps + the path's one
+    collective, ``barrier()``.  Returns ``(seconds as the MAX over the ranks, gathered frames on dst | None, info)``.
+
+    ``step(out)`` enqueues one pass of the hot path over this rank's ``b`` resident frames and leaves the finished uint8 frames
+    in ``out`` [b,H,W,3] (``block_shape`` = (b, H, W, 3)) - or returns another tensor of that shape if it cannot write in place.
+    Every step is a job of ``world * b`` frames cut into contiguous per-rank blocks (weak scaling); its frames meet on ``dst``:
+
+    mode "end"      (default) every rank keeps the frames of its ``steps`` steps in HBM ([steps * b, H, W, 3] uint8) and the timed
+                    region ENDS with ONE gather of the whole block - the region is one ``steps * world * b``-frame job in frame
+                    order, and no transport kernel ever runs beside the compute kernels (which fill every CU and cannot
+                    rebalance around a late start: tools/probes/notes/dynamic_tile_scheduling.md).
+    mode "overlap"  one asynchronous gather per step, at most two in flight: step k's gather overlaps step k+1's kernels.
+
+    ``gather=False`` (or a single process) runs the steps alone.  ``mark()`` / ``elapsed(a, b)`` are the engine's stream time stamps
+    (HIP events); the defaults use the host clock (CPU tests).  ``info`` = {"mode", "gathers", "compute_ms", "gather_ms",
+    "gather_bytes"}: compute_ms from the first step to the last kernel of the last step, gather_ms from there to the arrival of
+    the last gathered frame on this rank's stream (mode "overlap": the gathers of all but the last two steps lie inside compute_ms)."""
+    if mode not in GATHER_MODES:
+        raise ValueError(f"gather mode must be one of {GATHER_MODES}, got {mode!r}")
+    rank, world = _rank_world(group)
+    gathering = bool(gather) and sh.dist_on()
+    b = int(block_shape[0])
+    frame = tuple(int(v) for v in block_shape[1:])
+    mark = mark or time.perf_counter
+    elapsed = elapsed or (lambda a_, b_: b_ - a_)
+    info = {"mode": mode if gathering else None, "gathers": 0, "gather_bytes": 0}
+    n_end = steps * b
+    if gathering and mode == "end" and n_end * world * int(np.prod(frame)) > MAX_END_GATHER_BYTES:
+        raise ValueError(f"--gather end would collect {n_end * world * int(np.prod(frame)) / 2**30:.1f} GiB on rank {dst}: "
+                         "use fewer steps or the overlapped gather")
+    keep = torch.empty((max(n_end, b),) + frame, dtype=torch.uint8, device=device) if gathering and mode == "end" else None
+    # without a kept block a step writes into one of three rotating buffers: at most two gathers are in flight, so the buffer a
+    # step overwrites is the one whose gather was waited for (on the stream) a step ago
+    scratch = [torch.empty((b,) + frame, dtype=torch.uint8, device=device) for _ in range(3)] if keep is None else None
+    pending, got = [], [None]
+
+    def one(k):
+        slot = keep[(k % steps) * b:(k % steps + 1) * b] if keep is not None else scratch[k % 3]
+        out = step(slot)
+        if out is not None and out is not slot:
+            if tuple(out.shape) != tuple(slot.shape):
+                raise ValueError(f"step returned {tuple(out.shape)}, expected {tuple(slot.shape)}")
+            slot.copy_(out)
+        if gathering and mode == "overlap":
+            info["gathers"] += 1
+            info["gather_bytes"] += slot.numel()
+            pending.append(sh.gather_frames(slot, world * b, dst=dst, group=group, async_op=True, counts=[b] * world))
+            if len(pending) > 2:
+                got[0] = pending.pop(0)()
+
+    def finish():
+        while pending:
+            got[0] = pending.pop(0)()
+        if gathering and mode == "end":
+            info["gathers"] += 1
+            info["gather_bytes"] += n_end * int(np.prod(frame))
+            got[0] = sh.gather_frames(keep[:n_end], world * n_end, dst=dst, group=group, counts=[n_end] * world)
+
+    # warm-up: the steps, and - once - the collective in the very shape the timed region issues it (communicator set-up, the
+    # receive buffer's first allocation), all outside the timing
+    for k in range(warmup):
+        one(k)
+    if warmup > 0 or gathering:
+        finish()
+    got[0] = None
+    info["gathers"], info["gather_bytes"] = 0, 0
+    barrier()
+    t0 = time.perf_counter()
+    m0 = mark()
+    for k in range(steps):
+        one(k)
+    m1 = mark()
+    finish()
+    m2 = mark()
+    barrier()
+    dt = time.perf_counter() - t0
+    info["compute_ms"] = elapsed(m0, m1) * 1e3
+    info["gather_ms"] = elapsed(m1, m2) * 1e3
+    info["local_s"] = dt
+    if sh.dist_on() and dist.get_world_size(group) > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        if "cpu" not in sh.backend_table(group):
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        dt = float(t.item())
+    return dt, got[0], info

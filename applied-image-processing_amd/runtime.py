@@ -116,7 +116,11 @@ def is_diag():
     return hasattr(lib(), "adain_debug_set_conv_stamp_buffer")
 
 
+ABI_CALLS = [0]          # compute calls made through the C ABI by this process (jobs report it per frame)
+
+
 def _check(rc, what):
+    ABI_CALLS[0] += 1
     if rc != 0:
         raise AdainHipError(f"{what} failed ({rc}): {lib().adain_last_error().decode()}")
 

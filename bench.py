@@ -2,7 +2,9 @@
 """Throughput benchmark of the AdaIN hot path on MI355X (BASELINE.json metric: stylised Mpixels/s).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
-N > 1 is launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: one process per GPU.
+N > 1: one process per GPU.  Either launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``, or
+typed bare (``python bench.py --gpus N``): the bare process then starts N fresh rank processes itself BEFORE anything touches a
+GPU (subprocesses, never an exec), hands rank 0's JSON line through, and exits with the worst child's status.
 
 A "step" is one pass of the hot path over one batch of synthetic frames that are resident in HBM when the timed region starts:
   config 2 (default, BASELINE configs[1])  one full ``style_transfer_simple`` (reference Style_3DGS/AdaIN/test.py:74-81): encode the
@@ -14,8 +16,10 @@ A "step" is one pass of the hot path over one batch of synthetic frames that are
   config 5  one sub-batch of the 3DGS guide-view job (Style_3DGS/train.py:86-115): ``--batch`` masked 1200x1600 views per GPU per
             step, mask composite + uint8 out.  ``--job`` runs the whole 300-view job.
 With more than one rank (or under torch.distributed.run) the frame list of a step is cut into contiguous per-rank blocks
-(weak scaling: ``--batch`` frames per GPU) and every step ENDS with the path's one collective: the finished uint8 frames are
-gathered to rank 0 over RCCL (asynchronously: the gather of step k overlaps the compute of step k+1).  The
+(weak scaling: ``--batch`` frames per GPU) and the finished uint8 frames meet on rank 0 in the path's one collective, over
+RCCL: ``--gather end`` (default) keeps every rank's frames of the K timed steps in HBM and ENDS the timed region with ONE gather
+of them (the region is one K x N-frame job; no transport kernel ever runs beside the compute kernels); ``--gather overlap``
+issues one asynchronous gather per step (step k's overlaps step k+1's compute).  Both are inside the timing.  The
 device gather must run over RCCL ("nccl" backend): if the process group cannot provide it, or if there are more ranks than
 GPUs, the benchmark exits non-zero instead of silently degrading (``--rehearse`` allows both for single-GPU rehearsals and
 labels the JSON line).  The timed region is bracketed by barrier + synchronize; the MAX over ranks is reported.
@@ -53,6 +57,96 @@ sys.dont_write_bytecode = True
 # `hipIpcGetMemHandle: invalid argument`.  The launch environment exports it; kept here for a bare shell (it must be set before the
 # first HIP call of the process, i.e. before anything touches the GPU)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+
+def _argv_value(flag, default):
+    for i, a in enumerate(sys.argv):
+        if a == flag and i + 1 < len(sys.argv):
+            return sys.argv[i + 1]
+        if a.startswith(flag + "="):
+            return a.split("=", 1)[1]
+    return default
+
+
+def self_launch():
+    """``python bench.py --gpus N`` typed bare (no WORLD_SIZE / RANK in the environment) with N > 1: start N fresh rank processes -
+    one per GPU, LOCAL_RANK = RANK = 0..N-1, rendezvous on 127.0.0.1 - before this process has made any GPU call (it never makes
+    one), let rank 0's stdout (the one JSON line) through, wait, and exit with the worst child's status.  The first failing rank,
+    or the time limit (--launch-timeout seconds, default 1500), ends the whole group.  Never an exec: children are subprocesses."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    try:
+        n = int(_argv_value("--gpus", "1"))
+    except ValueError:
+        return                                   # argparse reports it
+    if n <= 1 or "-h" in sys.argv or "--help" in sys.argv:
+        return
+    import signal
+    import socket
+    import subprocess
+
+    limit = float(_argv_value("--launch-timeout", "1500"))
+    if "--rehearse" not in sys.argv:
+        import torch                              # device_count() only counts: it does not initialise HIP in this process
+
+        ndev = torch.cuda.device_count()
+        if ndev < n:
+            raise SystemExit(f"bench.py: --gpus {n} means {n} ranks, one per GPU, but {ndev} GPU(s) are visible here "
+                             "(--rehearse runs the multi-rank path with ranks sharing a GPU, labelled as a rehearsal)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ADAIN_SELF_LAUNCHED="1")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True,
+                                      stdout=None if r == 0 else sys.stderr))
+
+    def stop_all():
+        for sig, wait in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):
+            alive = [p for p in procs if p.poll() is None]
+            for p in alive:
+                try:
+                    os.killpg(p.pid, sig)         # each child leads its own session: exactly the processes started here
+                except (ProcessLookupError, PermissionError):
+                    pass
+            t_end = time.time() + wait
+            while time.time() < t_end and any(p.poll() is None for p in alive):
+                time.sleep(0.05)
+
+    def on_signal(signum, _frame):
+        stop_all()
+        os._exit(128 + signum)
+
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, on_signal)
+    t_end = time.time() + limit
+    worst = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            r, c = bad[0]
+            print(f"bench.py: rank {r} exited with status {c}: stopping the other ranks", file=sys.stderr, flush=True)
+            stop_all()
+            worst = c if c > 0 else 128 - c
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > t_end:
+            print(f"bench.py: the {n} ranks did not finish within {limit:.0f} s: stopping them", file=sys.stderr, flush=True)
+            stop_all()
+            worst = 124
+            break
+        time.sleep(0.1)
+    raise SystemExit(worst)
+
+
+if __name__ == "__main__":
+    self_launch()
 
 import numpy as np
 import torch
@@ -296,9 +390,9 @@ class Step:
             f = [x + y for x, y in zip(f, enc_conv3x3_flops(1, self.hs, self.ws))]
         return f + dec_conv3x3_flops(self.batch, self.hc, self.wc)
 
-    def run(self, timed=False, to_u8=False):
+    def run(self, timed=False, to_u8=False, u8_out=None):
         """Returns the float result (and the conv event pairs when ``timed``); ``self.u8`` holds the uint8 frames when the
-        config quantises (4, 5) or ``to_u8`` asks for it."""
+        config quantises (4, 5) or ``to_u8`` asks for it (written into ``u8_out`` [b,H,W,3] when given)."""
         ev = []
         self.edge_ev = []
         T = Timer(timed)
@@ -335,7 +429,7 @@ class Step:
             # F.interpolate calls of test.py:222-236 are identities and the engine skips them (engine.AdaINEngine.composite)
             out = T("mask_composite_kernel", 4 * px * 12, rt.mask_composite, self.content, out, self.mask)
         if self.config in (4, 5) or to_u8:
-            self.u8 = T("quantize_u8_kernel", px * 15, rt.quantize_u8, out)
+            self.u8 = T("quantize_u8_kernel", px * 15, rt.quantize_u8, out, u8_out)
         self.spans = T.spans
         return (out, ev) if timed else out
 
@@ -528,6 +622,12 @@ def parse_args():
     ap.add_argument("--host-frames", action="store_true",
                     help="--job: also time the job with its frames in host memory (pinned staging + copy stream) and the result copied back")
     ap.add_argument("--gather-chunks", type=int, default=1, help="--job: pieces the one gather is issued in (overlapping the remaining compute)")
+    ap.add_argument("--gather", choices=list(jobs.GATHER_MODES), default="end",
+                    help="more than one rank, per-step mode: 'end' (default) = ONE gather of every rank's frames of the K timed steps at the end "
+                         "of the timed region (no transport kernel beside the compute kernels); 'overlap' = one asynchronous gather per step")
+    ap.add_argument("--sustain", type=float, default=2.0, help="single GPU, per-step mode: also run the same loop for at least this many seconds "
+                    "after the timed region and report it as `sustained` (0 = skip)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="bare `--gpus N` launch: seconds after which the rank processes are stopped")
     ap.add_argument("--n1-value", type=float, default=0.0, help="--job: the 1-GPU value of the same job, to report efficiency_vs_n1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1080p pixel-kernel bandwidth table")
@@ -557,8 +657,8 @@ class Ctx:
         self.rank = rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if args.gpus != world:
-            if world == 1 and args.gpus > 1:
-                raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+            if world == 1 and args.gpus > 1:      # (unreachable from the command line: self_launch() starts the ranks)
+                raise SystemExit("bench.py --gpus N runs N rank processes: start it as a script, or under torch.distributed.run")
             args.gpus = world
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the AdaIN path has no CPU fallback)")
@@ -582,6 +682,32 @@ class Ctx:
             self.transport = "gloo" if self.shared_gpu else sh.device_transport(torch.empty(0, dtype=torch.uint8, device=self.device))
             if self.transport != "rccl" and not args.rehearse:
                 raise SystemExit(f"bench.py: the device gather would run over {self.transport!r}, not RCCL: refusing to report a multi-GPU number")
+        self.ranks = self.describe_ranks(local_rank % ndev)
+
+    def describe_ranks(self, dev_index):
+        """What the JSON line needs to show that the device transport really saw ``world`` ranks on ``world`` devices: every rank's
+        device (index, uuid, name), pid and host, collected with all_gather_object, the RCCL version, and the result of ONE
+        all_reduce(SUM) of a device-resident 1 per rank over the device transport (= world if every rank took part)."""
+        props = torch.cuda.get_device_properties(dev_index)
+        mine = {"rank": self.rank, "device": dev_index, "uuid": str(getattr(props, "uuid", "")), "name": props.name,
+                "gcn_arch": getattr(props, "gcnArchName", ""), "pid": os.getpid(), "host": os.uname().nodename}
+        if not self.use_dist:
+            return {"world": 1, "devices": [mine], "transport": None, "launcher": "single process"}
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine)
+        one = torch.ones(1, dtype=torch.int32, device=self.device)
+        if self.transport == "rccl":
+            dist.all_reduce(one)                      # device tensor: rides the cuda backend (RCCL)
+        else:
+            one = one.cpu()
+            dist.all_reduce(one)
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if self.transport == "rccl" else None
+        except Exception as e:                        # the proof above does not depend on it
+            ver = f"unavailable ({type(e).__name__})"
+        return {"world": self.world, "devices": everyone, "distinct_devices": len({(d["host"], d["uuid"] or d["device"]) for d in everyone}),
+                "transport": self.transport, "rccl": ver, "allreduce_of_ones": int(one.item()), "backend": str(dist.get_backend_config()),
+                "launcher": "bench.py self-launch" if os.environ.get("ADAIN_SELF_LAUNCHED") else "torch.distributed.run / external"}
 
     def barrier(self):
         torch.cuda.synchronize()                      # this rank's GPU work is done ...
@@ -647,8 +773,13 @@ def main_job(args, ctx):
         assert res is not None and res.shape == (n_total, h, w, 3), (None if res is None else res.shape)
     first_u8 = res[:2].clone() if rank == 0 else None
     per_rank = [None] * world
-    mine = {k: round(float(info[k]), 4) for k in ("compute_s", "gather_s", "enqueue_s", "fetch_s")}
+    mine = {k: round(float(info[k]), 4) for k in ("compute_s", "gather_s", "enqueue_s", "fetch_s", "host_cpu_s", "process_cpu_s")}
     mine["frames"] = hi - lo
+    if hi > lo:
+        # CPU the launching thread / the whole process spend per frame (eight ranks share one host), and C-ABI calls per frame
+        mine["launch_thread_cpu_ms_per_frame"] = round(info["host_cpu_s"] * 1e3 / (hi - lo), 4)
+        mine["process_cpu_ms_per_frame"] = round(info["process_cpu_s"] * 1e3 / (hi - lo), 4)
+        mine["abi_calls_per_frame"] = round(info["abi_calls"] / (hi - lo), 2)
     if ctx.use_dist:
         dist.all_gather_object(per_rank, mine)
     else:
@@ -689,6 +820,7 @@ def main_job(args, ctx):
         result["job"] = {"driver": "jobs.stylize_frames_sharded", "frames": n_total, "frames_per_rank": shard, "sub_batch": sub,
                          "gathers_per_job": info["gathers"], "gather_chunks": args.gather_chunks, "transport": ctx.transport,
                          "per_rank": per_rank, "ms_per_frame": round(sec_per_job * 1e3 / max(shard), 4)}
+        result["ranks"] = ctx.ranks
         if args.n1_value > 0:
             result["job"]["efficiency_vs_n1"] = round(value / (args.n1_value * world), 4)
         if args.rehearse:
@@ -725,49 +857,56 @@ def main():
     h, w, hs, ws = step.h, step.w, step.hs, step.ws
     n_job = world * args.batch                        # frames of one step's job over all ranks
 
-    pending = []
-    gathered = [None]
+    need_u8 = use_dist or args.config in (4, 5)
+    oh, ow = (8 * step.hc, 8 * step.wc) if args.config != 5 else (h, w)     # config 5 composites at the view's own size
 
-    def one_step():
+    def one_step(slot):
         # every config: the C-ABI call sequence of one forward on the step's resident frames (configs 4 / 5 end with their uint8
-        # quantiser / mask composite); whole jobs through the sharded driver are `--job`
-        out = step.run(to_u8=use_dist)
-        if use_dist:                                  # the path's one collective: finished uint8 frames -> rank 0
-            pending.append(sh.gather_frames(step.u8, n_job, dst=0, async_op=True))
-            if len(pending) > 2:                      # at most two gathers in flight: step k's overlaps step k+1's compute
-                gathered[0] = pending.pop(0)()
-        return out
+        # quantiser / mask composite; with more than one rank every config quantises - the gather moves uint8 frames); whole jobs
+        # through the sharded driver are `--job`
+        last[0] = step.run(to_u8=use_dist, u8_out=slot if need_u8 else None)
 
-    def drain():
-        while pending:
-            gathered[0] = pending.pop(0)()
-
+    last = [None]
     ctx.warm_transport(n_job, args.batch)
-    for _ in range(args.warmup):
-        out = one_step()
-    drain()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_step()
-    drain()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, gathered, tinfo = jobs.run_timed_steps(one_step, args.steps, args.warmup, barrier=barrier, block_shape=(args.batch, oh, ow, 3),
+                                               device=device, mode=args.gather, gather=use_dist, mark=step.engine.mark,
+                                               elapsed=step.engine.elapsed)
+    out = last[0]
+    per_rank = [None] * world
+    mine = {"rank": rank, "compute_ms": round(tinfo["compute_ms"], 3), "gather_ms": round(tinfo["gather_ms"], 3),
+            "wall_ms": round(tinfo["local_s"] * 1e3, 3)}
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        dist.all_gather_object(per_rank, mine)
         if rank == 0:
-            assert gathered[0] is not None and gathered[0].shape[0] == n_job
+            expect = n_job * (args.steps if args.gather == "end" else 1)
+            assert gathered is not None and gathered.shape[0] == expect, (None if gathered is None else gathered.shape, expect)
+    else:
+        per_rank = [mine]
+    del gathered
 
-    # one isolated gather (nothing else in flight) for the transport's own cost
+    # one isolated gather of one step's frames (nothing else in flight) for the transport's own cost
     gather_ms = None
     if use_dist:
         barrier()
         g0 = time.perf_counter()
-        sh.gather_frames(step.u8, n_job, dst=0)
+        sh.gather_frames(step.u8, n_job, dst=0, counts=[args.batch] * world)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+
+    sustained = None
+    if not use_dist and args.sustain > 0:
+        # the same loop, run for at least --sustain seconds straight after the timed region: the headline's K steps last well
+        # under a second at config 2, this says what the chip holds once clocks and temperature have settled
+        per = max(dt / args.steps, 1e-4)
+        k_s = int(math.ceil(args.sustain / per))
+        torch.cuda.synchronize()
+        s0 = time.perf_counter()
+        for _ in range(k_s):
+            one_step(None)
+        torch.cuda.synchronize()
+        sdt = time.perf_counter() - s0
+        sustained = {"seconds": round(sdt, 3), "steps": k_s, "value": round(n_job * h * w / 1e6 / (sdt / k_s), 3),
+                     "ms_per_step": round(sdt / k_s * 1e3, 4), "unit": "Mpixels/s"}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -775,14 +914,22 @@ def main():
         roof, layers, secondary = measure_roofline(step, 5)
         result = base_result(args, ctx, value, ms, WORKLOADS[args.config].format(h=h, w=w, hs=hs, ws=ws, b=args.batch, alpha=args.alpha)
                              + ("; depth-aware variant (a proximity map per frame, offset 0.30, prominence 20)" if args.depth else ""),
-                             f"frame sharding x{world}: contiguous frame blocks per rank, replicated weights and style "
-                             "statistics, one gather of the uint8 frames to rank 0 per step" if use_dist else "single GPU, no collective", "weak")
+                             f"frame sharding x{world}: contiguous frame blocks per rank, replicated weights and style statistics, "
+                             + ("ONE gather of the uint8 frames of all timed steps to rank 0 at the end of the timed region" if args.gather == "end"
+                                else "one gather of the uint8 frames to rank 0 per step (asynchronous)") if use_dist else "single GPU, no collective", "weak")
         result["roofline"] = roof
         result["secondary"] = secondary
         result["step_tflops"] = round(step.flops_per_step() / (dt / args.steps) / 1e12 * world, 2)
+        result["ranks"] = ctx.ranks
+        result["per_rank"] = per_rank
+        if sustained is not None:
+            sustained["ratio_to_value"] = round(sustained["value"] / value, 4)
+            result["sustained"] = sustained
         if use_dist:
-            result["gather"] = {"in_timed_step": True, "transport": transport, "isolated_ms": round(gather_ms, 3),
-                                "bytes_per_rank": int(step.u8.numel()), "overlapped_with_next_step": True}
+            result["gather"] = {"mode": args.gather, "in_timed_region": True, "transport": transport, "gathers_in_timed_region": tinfo["gathers"],
+                                "bytes_per_rank_in_timed_region": int(tinfo["gather_bytes"]), "isolated_one_step_ms": round(gather_ms, 3),
+                                "what": ("ONE gather of every rank's frames of all timed steps ends the timed region" if args.gather == "end"
+                                         else "one asynchronous gather per step, at most two in flight, overlapping the next step's compute")}
             if args.rehearse:
                 result["rehearsal"] = {"ranks_share_a_gpu": shared_gpu, "note": "not a multi-GPU measurement"}
         if args.pcie:

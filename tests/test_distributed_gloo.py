@@ -258,11 +258,11 @@ def test_timed_job_loop_one_gather_per_job(world, n, chunks):
     assert info["gathers"] == 0
 
 
-def _failing_worker(rank, world, port, mode, q):
+def _failing_worker(rank, world, port, mode, chunks, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        n = 7
+        n = 7 if chunks == 1 else 12
         frames, _ = _u8_inputs(n)
         if mode == "mixed":                                  # the last rank's block holds one frame of another size
             frames[n - 1] = frames[n - 1][:8]
@@ -272,32 +272,110 @@ def _failing_worker(rank, world, port, mode, q):
                 return n
 
             def __getitem__(self, k):
-                if mode == "raise" and k == 5:               # frame 5 belongs to the last rank
-                    raise OSError("cannot decode frame 5")
+                if mode.startswith("raise") and k == {"raise": n - 2, "raise_first": sh.shard_range(n, world, world - 1)[0]}[mode]:
+                    raise OSError(f"cannot decode frame {k}")      # a frame of the last rank's block (its first one: before any piece)
                 return frames[k]
 
+        style = torch.full((1, 3, 4, 4), 0.3)
+        kw = dict(sub_batch=1, gather_chunks=chunks, out_hw=(12, 20)) if chunks > 1 else dict(sub_batch=2)
+        sh.reset_calls()
         try:
-            jobs.stylize_frames_sharded(StubEngine(), Frames(), torch.full((1, 3, 4, 4), 0.3), sub_batch=2)
+            jobs.stylize_frames_sharded(StubEngine(), Frames(), style, **kw)
             got = "no error"
         except Exception as e:
             got = f"{type(e).__name__}: {e}"
+        # every rank issued the same collectives, whatever happened to its block: the in-loop pieces and the status word
+        calls = dict(sh.CALLS)
         outs = [None] * world
-        dist.all_gather_object(outs, got)
+        dist.all_gather_object(outs, (got, calls["gather"], calls["agree"]))
+        # ... and the process group is still usable: a good job on it straight away
+        good, _ = _u8_inputs(n)
+        res, info = jobs.stylize_frames_sharded(StubEngine(), good, style, **kw)
         if rank == 0:
+            ref, _ = jobs.stylize_frames_sharded(StubEngine(), good, style, sub_batch=3, gather=False)
+            lo, hi = info["shard"]
+            assert res.shape[0] == n and torch.equal(res[lo:hi], ref)
             q.put(outs)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["raise", "mixed"])
-def test_an_error_on_one_rank_raises_on_every_rank(mode):
-    """A decode error or a frame of another size in ONE rank's block must not leave the other ranks waiting in the gather."""
-    outs = _run(_failing_worker, 3, (mode,))
-    assert all(o != "no error" for o in outs), outs
-    if mode == "raise":
-        assert outs[2].startswith("OSError") and all(o.startswith("RuntimeError") for o in outs[:2]), outs
-    else:
-        assert all(o.startswith("ValueError") for o in outs), outs
+@pytest.mark.parametrize("mode,chunks", [("raise", 1), ("mixed", 1), ("raise", 3), ("raise_first", 2), ("mixed", 2)])
+def test_an_error_on_one_rank_raises_on_every_rank(mode, chunks):
+    """A decode error or a frame of another size in ONE rank's block must not leave the other ranks waiting in the gather - also
+    when the gather is issued in pieces inside the frame loop (the failing rank then sends zero-filled pieces: the collective
+    sequence stays the same on every rank, the status word raises everywhere, the group stays usable)."""
+    outs = _run(_failing_worker, 3, (mode, chunks))
+    errs = [o[0] for o in outs]
+    assert all(e != "no error" for e in errs), outs
+    assert len({o[1:] for o in outs}) == 1 and outs[0][1:] == (chunks - 1, 1), outs      # identical collectives on every rank
+    if mode.startswith("raise"):
+        assert errs[2].startswith("OSError") and all(e.startswith("RuntimeError") for e in errs[:2]), outs
+    elif chunks == 1:
+        assert all(e.startswith("ValueError") for e in errs), outs
+    else:           # pieces need out_hw: the rank holding the odd frame knows at once, the others learn it from the status word
+        assert errs[2].startswith("ValueError") and all(e.startswith("RuntimeError") for e in errs[:2]), outs
+
+
+def test_chunked_gather_without_out_hw_runs_as_one_gather():
+    frames, _ = _u8_inputs(4)
+    out, info = jobs.stylize_frames_sharded(StubEngine(), frames, torch.full((1, 3, 4, 4), 0.3), sub_batch=2, gather_chunks=3)
+    assert out.shape[0] == 4 and info["gathers"] == 0            # (single process: nothing to gather, no piece logic either)
+
+
+# ---- the timed per-step loop of bench.py (default mode with more than one rank): both gather modes, collectives counted -----------
+def _steps_worker(rank, world, port, mode, steps, warmup, b, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def step(slot):                    # "stylise" this rank's b resident frames: the result names rank, call and frame
+            k = len(calls)
+            calls.append(k)
+            for f in range(b):
+                slot[f].fill_((17 * rank + 5 * k + f) % 251)
+
+        barriers = []
+        sh.reset_calls()
+        dt, got, info = jobs.run_timed_steps(step, steps, warmup, barrier=lambda: (barriers.append(1), jobs.host_barrier()),
+                                             block_shape=(b, 4, 6, 3), device=torch.device("cpu"), mode=mode)
+        assert len(calls) == warmup + steps and len(barriers) == 2 and dt > 0
+        if mode == "end":                  # ONE gather in the timed region (and one, of the same shape, in the warm-up)
+            assert sh.CALLS["gather"] == 2 and info["gathers"] == 1 and info["gather_bytes"] == steps * b * 72
+        else:                              # one per step
+            assert sh.CALLS["gather"] == warmup + steps and info["gathers"] == steps and info["gather_bytes"] == steps * b * 72
+        assert sh.CALLS["agree"] == 0 and info["mode"] == mode
+        assert info["compute_ms"] >= 0 and info["gather_ms"] >= 0
+        if rank == 0:
+            q.put(got.clone())
+        else:
+            assert got is None
+        jobs.host_barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode,steps,warmup,b", [(2, "end", 4, 1, 1), (3, "end", 3, 2, 2), (2, "overlap", 5, 1, 1), (3, "overlap", 4, 0, 2),
+                                                       (2, "end", 2, 0, 1)])
+def test_timed_step_loop_gather_modes(world, mode, steps, warmup, b):
+    got = _run(_steps_worker, world, (mode, steps, warmup, b))
+    if mode == "end":                      # the timed region as ONE steps x world x b-frame job, in frame order: [rank][step][frame]
+        assert got.shape == (world * steps * b, 4, 6, 3)
+        want = [(17 * r + 5 * (warmup + k) + f) % 251 for r in range(world) for k in range(steps) for f in range(b)]
+    else:                                  # the last step's job
+        assert got.shape == (world * b, 4, 6, 3)
+        want = [(17 * r + 5 * (warmup + steps - 1) + f) % 251 for r in range(world) for f in range(b)]
+    assert got.reshape(got.shape[0], -1).eq(torch.tensor(want, dtype=torch.uint8)[:, None]).all()
+
+
+def test_timed_step_loop_single_process_and_bad_mode():
+    calls = []
+    dt, got, info = jobs.run_timed_steps(lambda slot: calls.append(1), 3, 2, barrier=lambda: None, block_shape=(1, 2, 2, 3),
+                                         device=torch.device("cpu"))
+    assert len(calls) == 5 and got is None and info["gathers"] == 0 and info["mode"] is None
+    with pytest.raises(ValueError):
+        jobs.run_timed_steps(lambda slot: None, 1, 0, barrier=lambda: None, block_shape=(1, 2, 2, 3), device=torch.device("cpu"), mode="both")
 
 
 def test_mixed_sizes_local_blocks_and_empty_job():
