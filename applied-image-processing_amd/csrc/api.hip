@@ -391,6 +391,125 @@ int adain_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, adain_
     return launch_nchw_to_nhwc(in, out, n, c, hw, (hipStream_t)stream);
 }
 
+// ---- one sub-batch of the batch callers in one call ---------------------------------------------------------------------------
+// Workspace of adain_stylize_u8, carved in this order (every block 256-byte aligned):
+struct StylizePlan {
+    int hc, wc, H8, W8;               // relu4_1 map; decoder output size (8hc x 8wc)
+    int identity;                     // mask, decoder output and frame share one size: the fused composite + quantise tail
+    size_t conv, feat, stat, stats_ws, pmap, pmap_ws, img, content, mask_f, mask_r, sty_r, comp, total;   // floats (conv / *_ws: bytes / 4)
+};
+static StylizePlan stylize_plan(int n, int h, int w, int use_depth, int mask_n, int mask_c, int mask_h, int mask_w, int mask_is_float) {
+    StylizePlan p{};
+    adain_encoded_size(h, w, &p.hc, &p.wc);
+    p.H8 = 8 * p.hc; p.W8 = 8 * p.wc;
+    const size_t enc = adain_encode_workspace_bytes(n, h, w), dec = adain_decode_workspace_bytes(n, p.hc, p.wc);
+    p.conv = align64(((enc > dec ? enc : dec) + 3) / 4);
+    p.feat = align64((size_t)n * p.hc * p.wc * 512);
+    p.stat = align64((size_t)n * 512);
+    p.stats_ws = align64((mean_std_workspace_bytes(1, n, 512, p.hc * p.wc) + 3) / 4);
+    if (use_depth) {
+        p.pmap = align64((size_t)n * p.hc * p.wc);
+        p.pmap_ws = align64((strength_map_workspace_bytes(p.hc, p.wc) + 3) / 4);
+    }
+    p.img = align64((size_t)n * 3 * p.H8 * p.W8);
+    if (mask_n > 0) {
+        p.identity = mask_h == h && mask_w == w && p.H8 == h && p.W8 == w;
+        if (!p.identity) {
+            p.content = align64((size_t)n * 3 * h * w);
+            p.mask_f = mask_is_float ? 0 : align64((size_t)mask_n * mask_c * mask_h * mask_w);
+            p.mask_r = (mask_h == h && mask_w == w) ? 0 : align64((size_t)mask_n * mask_c * h * w);
+            p.sty_r = (p.H8 == h && p.W8 == w) ? 0 : align64((size_t)n * 3 * h * w);
+            p.comp = align64((size_t)n * 3 * h * w);
+        }
+    }
+    p.total = p.conv + 2 * p.feat + 2 * p.stat + p.stats_ws + p.pmap + p.pmap_ws + p.img + p.content + p.mask_f + p.mask_r + p.sty_r + p.comp;
+    return p;
+}
+
+size_t adain_stylize_u8_workspace_bytes(int n, int h, int w, int use_depth, int mask_n, int mask_c, int mask_h, int mask_w, int mask_is_float) {
+    if (n < 1 || h < 9 || w < 9) return 0;
+    return stylize_plan(n, h, w, use_depth, mask_n, mask_c, mask_h, mask_w, mask_is_float).total * sizeof(float);
+}
+
+void adain_stylize_u8_out_size(int h, int w, int has_mask, int* oh, int* ow) {
+    int hc, wc;
+    adain_encoded_size(h, w, &hc, &wc);
+    if (oh) *oh = has_mask ? h : 8 * hc;
+    if (ow) *ow = has_mask ? w : 8 * wc;
+}
+
+int adain_stylize_u8(const uint8_t* frames, int n, int h, int w, const float* enc_packed, const float* dec_packed, const float* s_mean,
+                     const float* s_std, float alpha, float one_minus_alpha, const float* const* depth_maps, const int* depth_h, const int* depth_w,
+                     float depth_offset, float depth_prominence, const void* mask, int mask_is_float, int mask_n, int mask_c, int mask_h,
+                     int mask_w, uint8_t* out_u8, void* workspace, size_t ws_bytes, adain_stream_t stream) {
+    if (!frames || !enc_packed || !dec_packed || !s_mean || !s_std || !out_u8 || !workspace) { set_error("stylize_u8: null pointer"); return ADAIN_EINVAL; }
+    if (n < 1 || h < 9 || w < 9) { set_error("stylize_u8: frames %dx%d too small (needs h, w >= 9)", h, w); return ADAIN_EINVAL; }
+    if (!depth_maps && !(alpha >= 0.f && alpha <= 1.f)) { set_error("stylize_u8: alpha %g outside [0, 1]", alpha); return ADAIN_EINVAL; }   // test.py:75
+    if (depth_maps && (!depth_h || !depth_w)) { set_error("stylize_u8: depth maps without their sizes"); return ADAIN_EINVAL; }
+    if (depth_maps && !(depth_offset >= 0.f && depth_offset <= 1.f)) { set_error("stylize_u8: offset %g outside [0, 1]", depth_offset); return ADAIN_EINVAL; }   // test.py:56
+    if (!mask) mask_n = 0;
+    if (mask && ((mask_n != 1 && mask_n != n) || (mask_c != 1 && mask_c != 3) || mask_h < 1 || mask_w < 1)) {
+        set_error("stylize_u8: mask [%d][%d][%d][%d] does not fit %d RGB frames", mask_n, mask_c, mask_h, mask_w, n);
+        return ADAIN_EINVAL;
+    }
+    const StylizePlan p = stylize_plan(n, h, w, depth_maps != nullptr, mask_n, mask_c, mask_h, mask_w, mask_is_float);
+    if (ws_bytes < p.total * sizeof(float)) { set_error("stylize_u8: workspace too small (%zu < %zu bytes)", ws_bytes, p.total * sizeof(float)); return ADAIN_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    float* at = (float*)workspace;
+    auto take = [&at](size_t floats) { float* r = at; at += floats; return floats ? r : (float*)nullptr; };
+    float* conv = take(p.conv);
+    float* f = take(p.feat);
+    float* g = take(p.feat);
+    float* c_mean = take(p.stat);
+    float* c_std = take(p.stat);
+    float* stats_ws = take(p.stats_ws);
+    float* pmap = take(p.pmap);
+    float* pmap_ws = take(p.pmap_ws);
+    float* img = take(p.img);
+    float* content_f = take(p.content);
+    float* mask_f = take(p.mask_f);
+    float* mask_r = take(p.mask_r);
+    float* sty_r = take(p.sty_r);
+    float* comp = take(p.comp);
+    const int hw_c = p.hc * p.wc;
+
+    // vgg(content) with ToTensor inside the first layer (test.py:203-204, :57 / :76), calc_mean_std(content_f) (function.py:4-12)
+    RET_IF(adain_encode_u8(frames, f, enc_packed, conv, p.conv * sizeof(float), n, h, w, nullptr, stream));
+    RET_IF(launch_mean_std(f, 1, n, 512, hw_c, 1e-5f, c_mean, c_std, stats_ws, p.stats_ws * sizeof(float), s));
+    if (depth_maps) {       // compute_stylization_strength_map per frame, then AdaIN * (1 - P) + content_f * P (test.py:66-70)
+        for (int i = 0; i < n; ++i) {
+            if (!depth_maps[i]) { set_error("stylize_u8: depth map %d is null", i); return ADAIN_EINVAL; }
+            RET_IF(launch_strength_map(depth_maps[i], depth_h[i], depth_w[i], p.hc, p.wc, depth_offset, depth_prominence, pmap + (size_t)i * hw_c,
+                                       pmap_ws, p.pmap_ws * sizeof(float), s));
+        }
+        RET_IF(launch_adain_blend_ex(f, 1, n, 512, hw_c, c_mean, c_std, s_mean, s_std, 1, 0.f, 0.f, pmap, n, g, s));
+    } else {                // AdaIN * alpha + content_f * (1 - alpha) (test.py:79-80)
+        RET_IF(launch_adain_blend_ex(f, 1, n, 512, hw_c, c_mean, c_std, s_mean, s_std, 1, alpha, one_minus_alpha, nullptr, 1, g, s));
+    }
+    RET_IF(adain_decode(g, img, dec_packed, conv, p.conv * sizeof(float), n, p.hc, p.wc, nullptr, stream));     // test.py:71 / :81
+    if (mask_n == 0) return launch_quantize_u8(img, out_u8, n, 3, p.H8, p.W8, s);                                // test.py:243-244
+    if (p.identity)         // both F.interpolate calls of test.py:227-234 are identities: composite + quantise in one pass
+        return launch_composite_quantize_u8(frames, img, mask, mask_is_float, mask_c, mask_n, out_u8, n, h * w, s);
+    // the general composite (test.py:222-236): mask.float() -> nearest to the frame size; output -> bilinear to the frame size
+    RET_IF(launch_u8_to_f32(frames, content_f, n, 3, h, w, s));
+    const float* m = (const float*)mask;
+    if (!mask_is_float) {
+        RET_IF(launch_mask_to_f32((const uint8_t*)mask, mask_f, (size_t)mask_n * mask_c * mask_h * mask_w, s));
+        m = mask_f;
+    }
+    if (mask_r) {
+        RET_IF(launch_resize_nearest(m, mask_r, mask_n * mask_c, mask_h, mask_w, h, w, s));
+        m = mask_r;
+    }
+    const float* sty = img;
+    if (sty_r) {
+        RET_IF(launch_resize_bilinear(img, sty_r, n * 3, p.H8, p.W8, h, w, s));
+        sty = sty_r;
+    }
+    RET_IF(launch_mask_composite(content_f, sty, m, mask_c, mask_n, comp, n, 3, h * w, s));
+    return launch_quantize_u8(comp, out_u8, n, 3, h, w, s);
+}
+
 static unsigned long long* g_conv_dbg = nullptr;     // stamp buffer of the diagnostic kernels; always null in the product library
 
 size_t adain_conv3x3_wino4_packed_floats(int cin, int cout) { return (size_t)cin * cout * 24; }

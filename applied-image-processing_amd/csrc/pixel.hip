@@ -380,6 +380,85 @@ int launch_u8_to_f32(const uint8_t* in, float* out, int n, int c, int h, int w, 
     return check_launch("u8_to_f32");
 }
 
+// ---- the tail of a masked frame in one pass (adain_stylize_u8): ToTensor(content) -> content*(1-m) + stylized*m -> save_image's
+// quantiser (test.py:203-204, :236, :243-244) when mask, stylised frame and content already share one size.  The same
+// arithmetic, operation by operation, as u8_to_f32 -> mask.float() -> mask_composite -> quantize_u8 (this file compiles with
+// fp contraction off), so the bytes are identical to that sequence while a pixel moves 3 + 12 + 3|12 + 3 bytes instead of ~80.
+// content NHWC u8 [n][hw][3]; sty NCHW f32 [n][3][hw]; mask [mask_n][mask_c][hw] of MaskT (uint8 / bool bytes -> float(v), or
+// float); out NHWC u8 [n][hw][3].  blockIdx.y = image.
+template <typename MaskT>
+__device__ __forceinline__ float mask_val(const MaskT* __restrict__ p, size_t i) { return (float)p[i]; }
+
+template <typename MaskT, bool VEC4>
+__global__ __launch_bounds__(256) void composite_quantize_u8_kernel(const uint8_t* __restrict__ content, const float* __restrict__ sty,
+                                                                    const MaskT* __restrict__ mask, int mask_c, int mask_n,
+                                                                    uint8_t* __restrict__ out, int hw) {
+    const unsigned img = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const MaskT* __restrict__ mp = mask + (size_t)(mask_n == 1 ? 0u : img) * mask_c * hw;
+    const size_t mstep = mask_c == 1 ? 0 : (size_t)hw;
+    const float* __restrict__ sp = sty + (size_t)img * 3 * hw;
+    if (VEC4) {
+        if (q * 4 >= hw) return;
+        using u32x3 = __attribute__((ext_vector_type(3))) unsigned;
+        const u32x3 cw = *(const u32x3*)(content + ((size_t)img * hw + q * 4) * 3);
+        unsigned by[12];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const f32x4 b = *(const f32x4*)(sp + (size_t)ch * hw + q * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = 3 * k + ch;
+                const float a = __fdiv_rn((float)((cw[e >> 2] >> (8 * (e & 3))) & 255u), 255.0f);
+                const float m = mask_val(mp + ch * mstep, (size_t)q * 4 + k);
+                by[e] = quant1(a * (1.0f - m) + b[k] * m);
+            }
+        }
+        u32x3 w;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) w[d] = by[4 * d] | (by[4 * d + 1] << 8) | (by[4 * d + 2] << 16) | (by[4 * d + 3] << 24);
+        *(u32x3*)(out + ((size_t)img * hw + q * 4) * 3) = w;
+    } else {
+        if (q >= hw) return;
+        const uint8_t* __restrict__ cp = content + ((size_t)img * hw + q) * 3;
+        uint8_t* __restrict__ o = out + ((size_t)img * hw + q) * 3;
+        for (int ch = 0; ch < 3; ++ch) {
+            const float a = __fdiv_rn((float)cp[ch], 255.0f), m = mask_val(mp + ch * mstep, (size_t)q);
+            o[ch] = (uint8_t)quant1(a * (1.0f - m) + sp[(size_t)ch * hw + q] * m);
+        }
+    }
+}
+
+int launch_composite_quantize_u8(const uint8_t* content, const float* stylized, const void* mask, int mask_is_float, int mask_c,
+                                 int mask_n, uint8_t* out, int n, int hw, hipStream_t s) {
+    if (n < 1 || hw < 1) { set_error("composite_quantize_u8: bad shape"); return -1; }
+    if (mask_c != 1 && mask_c != 3) { set_error("composite_quantize_u8: mask channels %d must be 1 or 3", mask_c); return -1; }
+    if (mask_n != 1 && mask_n != n) { set_error("composite_quantize_u8: mask batch %d must be 1 or %d", mask_n, n); return -1; }
+    if ((size_t)hw * 3 >= 0x7fffffffULL || n > 65535) { set_error("composite_quantize_u8: frame too large or batch > 65535"); return -1; }
+    const bool vec = hw % 4 == 0 && aligned16(stylized) && ((uintptr_t)content & 3) == 0 && ((uintptr_t)out & 3) == 0;
+    const dim3 g((unsigned)(((size_t)hw / (vec ? 4 : 1) + 255) / 256), n);
+    if (mask_is_float) {
+        if (vec) hipLaunchKernelGGL((composite_quantize_u8_kernel<float, true>), g, dim3(256), 0, s, content, stylized, (const float*)mask, mask_c, mask_n, out, hw);
+        else hipLaunchKernelGGL((composite_quantize_u8_kernel<float, false>), g, dim3(256), 0, s, content, stylized, (const float*)mask, mask_c, mask_n, out, hw);
+    } else {
+        if (vec) hipLaunchKernelGGL((composite_quantize_u8_kernel<uint8_t, true>), g, dim3(256), 0, s, content, stylized, (const uint8_t*)mask, mask_c, mask_n, out, hw);
+        else hipLaunchKernelGGL((composite_quantize_u8_kernel<uint8_t, false>), g, dim3(256), 0, s, content, stylized, (const uint8_t*)mask, mask_c, mask_n, out, hw);
+    }
+    return check_launch("composite_quantize_u8");
+}
+
+// mask.float() of a uint8 / bool mask (test.py:224-226): float(v), element by element
+__global__ __launch_bounds__(256) void mask_to_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) out[i] = (float)in[i];
+}
+
+int launch_mask_to_f32(const uint8_t* in, float* out, size_t total, hipStream_t s) {
+    if (total < 1 || total >= ((size_t)1 << 39)) { set_error("mask_to_f32: bad size"); return -1; }
+    hipLaunchKernelGGL(mask_to_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total);
+    return check_launch("mask_to_f32");
+}
+
 // ---- video post-pass (reference video/utils.py:89-105 warp_image, :223-229 blend_images) -------------------
 // out = u8( clip( (alpha * cur/255 + (1 - alpha) * warp(prev)/255) * 255, 0, 255 ) ), HWC uint8 frames;
 // warp(prev)(y, x) = bilinear sample of prev at (x + flow[0][y][x], y + flow[1][y][x]) with cv2.BORDER_REFLECT

@@ -87,6 +87,22 @@ class AdaINEngine:
             g = rt.blend_alpha(f, True, c_mean, c_std, self.s_mean, self.s_std, alpha)
         return rt.decode(g, self.dec)
 
+    def stylize_u8(self, frames_u8, alpha=0.5, depth_maps=None, offset=0.15, prominence=20, masks=None, out=None):
+        """A sub-batch of decoded frames uint8 [n,h,w,3] -> finished uint8 frames [n,H,W,3] in ONE call of the C ABI
+        (``adain_stylize_u8``): what ``stylize`` / ``stylize_depth`` -> ``composite`` -> ``to_u8`` give, byte for byte, with one
+        Python -> C transition per sub-batch instead of eight (the job drivers' launching thread is what eight ranks share)."""
+        if self.s_mean is None:
+            raise rt.AdainHipError("set_style() first")
+        assert 0.0 <= alpha <= 1.0 and 0.0 <= offset <= 1.0
+        if depth_maps is not None:
+            depth_maps = [d.to(self.device, torch.float32) for d in depth_maps]
+        if masks is not None:
+            masks = masks.to(self.device)
+            if masks.dtype not in (torch.uint8, torch.bool, torch.float32):
+                masks = masks.float()
+        return rt.stylize_u8(frames_u8.to(self.device), self.enc, self.dec, self.s_mean, self.s_std, alpha, depth_maps, offset, prominence,
+                             masks, out)
+
     def stylize_depth(self, content, depth_maps, offset=0.15, prominence=20):
         """Depth-aware path for a batch: ``depth_maps`` is a list of [h0,w0] GPU tensors, one per frame."""
         assert 0.0 <= offset <= 1.0

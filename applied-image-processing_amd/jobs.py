@@ -607,16 +607,23 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
                     stats[cur_style] = engine.set_style(style_list[cur_style]).style_stats()
                 engine.use_style_stats(stats[cur_style])
             content = batch.content
-            if batch.depth is not None:
+            one_call = getattr(engine, "stylize_u8", None)
+            if (one_call is not None and content.dtype == torch.uint8 and content.dim() == 4 and content.shape[-1] == 3
+                    and not isinstance(batch.mask, list)):
+                # decoded RGB frames with (at most) one mask tensor for the sub-batch: the whole chain in one C-ABI call
+                u8 = one_call(content, alpha=alpha, depth_maps=batch.depth, offset=depth_offset, prominence=depth_prominence, masks=batch.mask)
+                out = None
+            elif batch.depth is not None:
                 out = engine.stylize_depth(content, [d.to(dev, torch.float32) for d in batch.depth], depth_offset, depth_prominence)
             else:
                 out = engine.stylize(content, alpha)
-            if isinstance(batch.mask, list):       # masks of different sizes inside one sub-batch: composite frame by frame
-                out = torch.cat([engine.composite(content[k:k + 1], out[k:k + 1], m.to(dev).float().unsqueeze(0))
-                                 for k, m in enumerate(batch.mask)])
-            elif batch.mask is not None:
-                out = engine.composite(content, out, batch.mask.to(dev).float())
-            u8 = engine.to_u8(out)
+            if out is not None:
+                if isinstance(batch.mask, list):       # masks of different sizes inside one sub-batch: composite frame by frame
+                    out = torch.cat([engine.composite(content[k:k + 1], out[k:k + 1], m.to(dev).float().unsqueeze(0))
+                                     for k, m in enumerate(batch.mask)])
+                elif batch.mask is not None:
+                    out = engine.composite(content, out, batch.mask.to(dev).float())
+                u8 = engine.to_u8(out)
             feeder.release(batch)
             if post is not None:
                 u8 = post(u8)

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_PKG, "libadain_hip.so")
 DIAG_LIB_PATH = os.path.join(_PKG, "libadain_hip_diag.so")
 
 SRC_DIRECT, SRC_UP2X, SRC_POOL2 = 0, 1, 2
+ABI_VERSION = 2          # ADAIN_ABI_VERSION of include/adain_hip.h this binding was written against
 
 _c_int, _c_float, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 _PP = ctypes.POINTER(ctypes.c_void_p)
@@ -54,6 +55,11 @@ SIGNATURES = {
     "adain_u8_to_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_warp_blend_u8": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p]),
     "adain_resize_area_u8": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 6 + [_c_void_p]),
+    "adain_stylize_u8_workspace_bytes": (_c_size_t, [_c_int] * 9),
+    "adain_stylize_u8_out_size": (None, [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
+    "adain_stylize_u8": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_float, _PP,
+                                  ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), _c_float, _c_float, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                                  _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "adain_nhwc_to_nchw": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_nchw_to_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_conv3x3_wino4_packed_floats": (_c_size_t, [_c_int, _c_int]),
@@ -97,8 +103,9 @@ def lib():
                 for name, (res, args) in sigs.items():
                     f = getattr(l, name)
                     f.restype, f.argtypes = res, args
-                if l.adain_abi_version() != 1:
-                    raise AdainHipError("libadain_hip.so ABI version mismatch")
+                if l.adain_abi_version() != ABI_VERSION:
+                    raise AdainHipError(f"{LIB_PATH}: ABI version {l.adain_abi_version()}, this binding needs {ABI_VERSION} "
+                                        "(rebuild: python applied-image-processing_amd/build.py)")
                 _lib = l
     return _lib
 
@@ -398,6 +405,57 @@ def quantize_u8(img, out=None):
         raise AdainHipError(f"quantize_u8: out must be a contiguous uint8 {(n, h, w, c)} tensor on {img.device}")
     with torch.cuda.device(img.device):
         _check(lib().adain_quantize_u8(img.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "adain_quantize_u8")
+    return out
+
+
+def stylize_u8(frames_u8, enc_packed, dec_packed, s_mean, s_std, alpha=0.5, depth_maps=None, depth_offset=0.15, depth_prominence=20,
+               mask=None, out=None):
+    """One sub-batch of decoded frames through the whole path in ONE call of the C ABI (``adain_stylize_u8``: ToTensor + encoder,
+    statistics, AdaIN blend - the alpha form, or the depth-aware form when ``depth_maps`` (one [h0,w0] float GPU tensor per frame)
+    are given - decoder, mask composite, uint8 quantiser); the bytes the separate calls give.  frames_u8 uint8 [n,h,w,3]; s_mean /
+    s_std [1,512]; mask [1|n, 1|3, hm, wm] uint8 / bool / float32 on the GPU.  Returns uint8 [n,oh,ow,3] (``out`` if given)."""
+    x = _dev(frames_u8, "frames", torch.uint8)
+    if x.dim() != 4 or x.shape[3] != 3:
+        raise AdainHipError(f"stylize_u8: expected uint8 [n,h,w,3], got {tuple(x.shape)}")
+    n, h, w, _ = x.shape
+    dev = x.device
+    s_mean, s_std = _dev(s_mean, "s_mean"), _dev(s_std, "s_std")
+    if s_mean.numel() != 512 or s_std.numel() != 512:
+        raise AdainHipError("stylize_u8: the style statistics must be [1,512] each (one style per call)")
+    mn = mc = mh = mw = 0
+    m_float, m_ptr = 0, None
+    if mask is not None:
+        if not isinstance(mask, torch.Tensor) or not mask.is_cuda or mask.dim() != 4:
+            raise AdainHipError("stylize_u8: mask must be a GPU tensor [1|n, 1|3, hm, wm]")
+        if mask.dtype == torch.float32:
+            m_float = 1
+        elif mask.dtype not in (torch.uint8, torch.bool):
+            raise AdainHipError(f"stylize_u8: mask dtype {mask.dtype} (uint8, bool or float32)")
+        mask = mask.contiguous()
+        mn, mc, mh, mw = mask.shape
+        m_ptr = mask.data_ptr()
+    dp = dh = dw = None
+    if depth_maps is not None:
+        depth_maps = [_dev(d, "depth_map") for d in depth_maps]
+        if len(depth_maps) != n or any(d.dim() != 2 for d in depth_maps):
+            raise AdainHipError(f"stylize_u8: need {n} depth maps [h0,w0], one per frame")
+        dp, _keep = _ptr_array(depth_maps)
+        dh = (_c_int * n)(*[d.shape[0] for d in depth_maps])
+        dw = (_c_int * n)(*[d.shape[1] for d in depth_maps])
+    oh, ow = ctypes.c_int(), ctypes.c_int()
+    L = lib()
+    L.adain_stylize_u8_out_size(h, w, int(mask is not None), ctypes.byref(oh), ctypes.byref(ow))
+    shape = (n, oh.value, ow.value, 3)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.uint8, device=dev)
+    elif not out.is_cuda or out.dtype != torch.uint8 or tuple(out.shape) != shape or not out.is_contiguous() or out.device != dev:
+        raise AdainHipError(f"stylize_u8: out must be a contiguous uint8 {shape} tensor on {dev}")
+    nbytes = L.adain_stylize_u8_workspace_bytes(n, h, w, int(depth_maps is not None), mn, mc, mh, mw, m_float)
+    ws = workspace(dev, "stylize", nbytes)
+    with torch.cuda.device(dev):
+        _check(L.adain_stylize_u8(x.data_ptr(), n, h, w, enc_packed.data_ptr(), dec_packed.data_ptr(), s_mean.data_ptr(), s_std.data_ptr(),
+                                  float(alpha), float(1 - alpha), dp, dh, dw, float(depth_offset), float(depth_prominence), m_ptr, m_float,
+                                  mn, mc, mh, mw, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "adain_stylize_u8")
     return out
 
 

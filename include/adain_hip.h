@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define ADAIN_ABI_VERSION 1
+/* 2: adain_encode_u8, adain_u8_to_f32 and adain_stylize_u8* added; the direct / F(2x2,3x3) single-layer entry points moved to
+ * the diagnostic library (include/adain_hip_diag.h); adain_conv3x3_wino accepts form 5 only.  Version 1 was never frozen. */
+#define ADAIN_ABI_VERSION 2
 #define ADAIN_OK 0
 #define ADAIN_EINVAL (-1)  /* bad argument / unsupported shape */
 #define ADAIN_ELAUNCH (-2) /* HIP reported a launch error */
@@ -148,6 +150,38 @@ ADAIN_API int adain_warp_blend_u8(const uint8_t* cur_u8, const uint8_t* prev_u8,
  * pixels). */
 ADAIN_API int adain_resize_area_u8(const uint8_t* in_u8, uint8_t* out_u8, int n, int hi, int wi, int c, int ho, int wo,
                          adain_stream_t stream);
+
+/* ---- one sub-batch of the reference's batch callers in ONE call ---------------------------------------------------------------
+ * What adain_inference does between `Image.open` and `save_image` for n decoded frames of one size and one style whose
+ * statistics are already known (test.py:203-244 per frame; the callers loop over frames with the same style,
+ * video/utils.py:341-350 and Style_3DGS/train.py:101):
+ *     ToTensor + vgg(content)                     adain_encode_u8        test.py:203-204, :57 / :76
+ *     calc_mean_std(content_f)                    adain_mean_std         function.py:4-12
+ *     depth_maps == NULL:  AdaIN*alpha + content_f*one_minus_alpha       test.py:79-80    (adain_blend_alpha; the caller passes
+ *                          float(1 - alpha) computed in double, as the reference's Python scalar is)
+ *     depth_maps != NULL:  P = strength map of depth_maps[i] [depth_h[i]][depth_w[i]] per frame (adain_strength_map,
+ *                          test.py:66-67), AdaIN*(1-P) + content_f*P     test.py:69-70    (adain_blend_pmap); alpha unused
+ *     decoder(feat)                               adain_decode           test.py:71 / :81
+ *     mask != NULL:  content*(1-m) + out*m with m = nearest(mask.float()) and out = bilinear(out), both to the frame's size
+ *                                                                        test.py:222-236  (adain_resize_* + adain_mask_composite)
+ *     x*255 + 0.5, clamp, uint8 HWC                adain_quantize_u8      test.py:243-244
+ * Every stage runs the kernel of the entry point named beside it with the same arguments, so `out_u8` holds the bytes that
+ * sequence of calls gives; when mask, decoder output and frame share one size (the usual case: sides that are multiples of 8,
+ * a mask made from the frame itself) the composite's three passes and the quantiser run as one kernel with the same arithmetic.
+ * frames HWC uint8 [n][h][w][3]; s_mean / s_std [512]: the style's statistics (adain_encode + adain_mean_std of the style
+ * image, once per style); depth_maps / depth_h / depth_w: HOST arrays of n device pointers / sizes; mask [mask_n][mask_c]
+ * [mask_h][mask_w], mask_n in {1, n}, mask_c in {1, 3}, uint8 / bool bytes (mask_is_float == 0) or float; out_u8 HWC uint8
+ * [n][oh][ow][3] with (oh, ow) = adain_stylize_u8_out_size: the frame's size with a mask, 8hc x 8wc without.  One workspace
+ * (adain_stylize_u8_workspace_bytes) holds every intermediate.  ~27 kernel launches, no allocation, no synchronisation. */
+ADAIN_API size_t adain_stylize_u8_workspace_bytes(int n, int h, int w, int use_depth, int mask_n, int mask_c, int mask_h, int mask_w,
+                                        int mask_is_float);
+ADAIN_API void adain_stylize_u8_out_size(int h, int w, int has_mask, int* oh, int* ow);
+ADAIN_API int adain_stylize_u8(const uint8_t* frames_nhwc_u8, int n, int h, int w, const float* enc_packed, const float* dec_packed,
+                     const float* s_mean, const float* s_std, float alpha, float one_minus_alpha,
+                     const float* const* depth_maps_host_array_of_dev_ptrs,
+                     const int* depth_h_host, const int* depth_w_host, float depth_offset, float depth_prominence, const void* mask,
+                     int mask_is_float, int mask_n, int mask_c, int mask_h, int mask_w, uint8_t* out_u8, void* workspace,
+                     size_t workspace_bytes, adain_stream_t stream);
 
 /* ---- layout changes at the boundary ([n][c][hw] <-> [n][hw][c]) ------------------------------------------ */
 ADAIN_API int adain_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, adain_stream_t stream);

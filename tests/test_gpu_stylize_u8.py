@@ -1,0 +1,151 @@
+"""GPU tests of ``adain_stylize_u8`` (round 4): one sub-batch of decoded frames through the whole path in ONE call of the C ABI
+must give the bytes of the separate calls it replaces (encode_u8 -> mean_std -> blend -> decode -> [composite] -> quantize_u8),
+for the alpha and the depth-aware blend, with and without masks, in the fused tail (mask, frame and decoder output of one size)
+and the general one (resizes), and against the CPU oracle.  Run with ``-m gpu``."""
+import numpy as np
+import pytest
+import torch
+
+import applied_image_processing_amd.synth as synth
+from oracle import adain_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def u8frames(seed, n, h, w):
+    return T(np.stack([(synth.image(seed + i, 1, h, w)[0].transpose(1, 2, 0) * 255).astype(np.uint8) for i in range(n)]))
+
+
+@pytest.fixture(scope="module")
+def rt():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import applied_image_processing_amd.runtime as rt
+
+    rt.lib()
+    return rt
+
+
+@pytest.fixture(scope="module")
+def engine(weights):
+    from applied_image_processing_amd.engine import AdaINEngine
+
+    eng = AdaINEngine(weights[0], weights[1], "cuda:0")
+    eng.set_style(T(synth.image(4, 1, 96, 128)).cuda())
+    return eng
+
+
+def separate_calls(engine, frames, alpha=0.5, depth=None, offset=0.15, prominence=20, masks=None):
+    """The call sequence the job drivers ran before the single entry point existed."""
+    if depth is not None:
+        out = engine.stylize_depth(frames, depth, offset, prominence)
+    else:
+        out = engine.stylize(frames, alpha)
+    if masks is not None:
+        out = engine.composite(frames, out, masks.float())
+    return engine.to_u8(out)
+
+
+@pytest.mark.parametrize("n,h,w,alpha", [(1, 64, 96, 0.5), (2, 45, 67, 0.3), (3, 128, 72, 1.0), (1, 264, 200, 0.0)])
+def test_alpha_blend_one_call_equals_separate_calls(engine, n, h, w, alpha):
+    x = u8frames(700 + h, n, h, w).cuda()
+    got = engine.stylize_u8(x, alpha=alpha)
+    hc, wc = -(-h // 8), -(-w // 8)
+    assert got.shape == (n, 8 * hc, 8 * wc, 3) and got.dtype == torch.uint8
+    assert torch.equal(got, separate_calls(engine, x, alpha))
+    buf = torch.zeros_like(got)
+    assert engine.stylize_u8(x, alpha=alpha, out=buf) is buf and torch.equal(buf, got)
+
+
+def test_depth_aware_one_call_equals_separate_calls_and_oracle(engine, weights):
+    n, h, w = 2, 96, 136
+    x = u8frames(720, n, h, w).cuda()
+    depth = [T(synth.smooth_depth(6 + i, h0, w0)).cuda() for i, (h0, w0) in enumerate([(96, 136), (50, 70)])]     # maps of two sizes
+    got = engine.stylize_u8(x, depth_maps=depth, offset=0.3, prominence=20)
+    assert torch.equal(got, separate_calls(engine, x, depth=depth, offset=0.3))
+    style = T(synth.image(4, 1, 96, 128))
+    for i in range(n):
+        c = x[i:i + 1].cpu().permute(0, 3, 1, 2).float().div(255)
+        with torch.no_grad():
+            ref = O.quantize_u8(O.style_transfer(weights[0], weights[1], c, style, depth[i].cpu(), 1.0, 0.3, 20))
+        assert (got[i].cpu().int() - ref[0].int()).abs().max() <= 1
+
+
+@pytest.mark.parametrize("mask_kind", ["bool3", "u8_1", "float3", "one_for_all"])
+def test_masked_frames_fused_tail_equals_separate_calls(engine, mask_kind):
+    n, h, w = 2, 64, 104                      # multiples of 8: mask, frame and decoder output share one size -> the fused kernel
+    x = u8frames(740, n, h, w).cuda()
+    if mask_kind == "bool3":
+        m = (x > 60).permute(0, 3, 1, 2).contiguous()                       # train.py:97: view > 0 style mask, [n,3,h,w] bool
+    elif mask_kind == "u8_1":
+        m = (x[..., :1] > 90).permute(0, 3, 1, 2).to(torch.uint8).contiguous()      # localized_style_transfer.py:186: [n,1,h,w] uint8
+    elif mask_kind == "float3":
+        m = T(synth.image(9, n, h, w)).cuda()                               # fractional float mask: every rounding step matters
+    else:
+        m = (x[:1] > 128).permute(0, 3, 1, 2).contiguous()                  # one mask for the whole sub-batch
+    got = engine.stylize_u8(x, alpha=0.5, masks=m)
+    assert got.shape == (n, h, w, 3)
+    assert torch.equal(got, separate_calls(engine, x, 0.5, masks=m))
+
+
+@pytest.mark.parametrize("h,w,mh,mw", [(45, 67, 45, 67), (64, 104, 32, 52), (50, 70, 25, 35)])
+def test_masked_frames_general_tail_equals_separate_calls(engine, h, w, mh, mw):
+    """Frame sides that are not multiples of 8 (the decoder's output is larger: bilinear resize) and masks of another size
+    (nearest resize): the tail of test.py:222-236 kernel by kernel."""
+    n = 2
+    x = u8frames(760 + h, n, h, w).cuda()
+    m = (T(synth.image(11, n, mh, mw)) > 0.4).cuda()
+    got = engine.stylize_u8(x, alpha=0.5, masks=m)
+    assert got.shape == (n, h, w, 3)
+    assert torch.equal(got, separate_calls(engine, x, 0.5, masks=m))
+    mu8 = m.to(torch.uint8)
+    assert torch.equal(engine.stylize_u8(x, alpha=0.5, masks=mu8), got)
+
+
+def test_full_size_view_with_mask_against_oracle(engine, weights):
+    h, w = 1200, 1600                         # BASELINE configs[4] view
+    x = u8frames(780, 1, h, w)
+    x[0][T(synth.uniform01(2000, h * w).reshape(h, w) < 0.3)] = 0
+    xd = x.cuda()
+    m = (xd > 0).permute(0, 3, 1, 2).contiguous()
+    got = engine.stylize_u8(xd, alpha=0.5, masks=m)
+    assert torch.equal(got, separate_calls(engine, xd, 0.5, masks=m))
+    c = x.permute(0, 3, 1, 2).float().div(255)
+    with torch.no_grad():
+        ref = O.quantize_u8(O.mask_composite(c, O.style_transfer_simple(weights[0], weights[1], c, T(synth.image(4, 1, 96, 128)), 0.5), (c[0] > 0)))
+    d = (got[0].cpu().int() - ref[0].int()).abs()
+    assert d.max() <= 1 and float((d > 0).float().mean()) < 1e-3
+
+
+def test_bad_arguments_raise(rt, engine):
+    x = u8frames(790, 1, 32, 32).cuda()
+    with pytest.raises(rt.AdainHipError):
+        rt.stylize_u8(x.cpu(), engine.enc, engine.dec, engine.s_mean, engine.s_std)      # no CPU fallback
+    with pytest.raises(rt.AdainHipError):
+        rt.stylize_u8(x, engine.enc, engine.dec, engine.s_mean, engine.s_std, depth_maps=[])      # one map per frame
+    with pytest.raises(rt.AdainHipError):
+        engine.stylize_u8(x, masks=torch.zeros(1, 2, 32, 32, device="cuda"))  # mask channels 1 or 3
+    with pytest.raises(rt.AdainHipError):
+        engine.stylize_u8(u8frames(791, 1, 8, 8).cuda())                      # relu4_1 would be 1 x 1 (torch raises there too)
+    with pytest.raises(AssertionError):
+        engine.stylize_u8(x, alpha=1.5)                                      # test.py:75
+
+
+def test_job_driver_uses_the_single_call_and_gives_the_same_frames(rt, engine):
+    import applied_image_processing_amd.jobs as jobs
+
+    n, h, w = 5, 64, 96
+    frames = [f.numpy() for f in u8frames(800, n, h, w)]
+    masks = [(f > 50).transpose(2, 0, 1) for f in frames]
+    style = T(synth.image(4, 1, 96, 128)).cuda()
+    before = rt.ABI_CALLS[0]
+    out, info = jobs.stylize_frames_sharded(engine, frames, style, alpha=0.5, masks=masks, sub_batch=2, style_cache={0: engine.style_stats()})
+    assert info["abi_calls"] == rt.ABI_CALLS[0] - before == 3             # three sub-batches, ONE C-ABI call each
+    engine.use_style_stats(engine.style_stats())
+    want = torch.cat([separate_calls(engine, T(np.stack(frames[i:i + 2])).cuda(), 0.5, masks=T(np.stack(masks[i:i + 2])).cuda())
+                      for i in range(0, n, 2)])
+    assert torch.equal(out, want)
+    assert info["host_cpu_s"] >= 0 and info["process_cpu_s"] >= info["host_cpu_s"] * 0.5

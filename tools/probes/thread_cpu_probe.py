@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Where does the CPU time of a job go, thread by thread?  Runs the 1080p video job (device-resident frames, then host-resident
+frames) through ``jobs.stylize_frames_sharded`` and reads /proc/self/task/*/stat around it: CPU seconds per thread (named threads of
+this package, the Python main thread, and whatever the HIP runtime starts), per frame.  Eight ranks share one host: this is what
+each of them costs it.
+
+    python tools/probes/thread_cpu_probe.py [--frames 96] [--env HIP_FORCE_... (none needed)]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import torch
+
+import bench
+import applied_image_processing_amd.engine as engine_mod
+import applied_image_processing_amd.jobs as jobs
+import applied_image_processing_amd.synth as synth
+
+TICK = os.sysconf("SC_CLK_TCK")
+
+
+def threads():
+    out = {}
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            s = open(f"/proc/self/task/{tid}/stat").read()
+        except OSError:
+            continue
+        name = s[s.index("(") + 1:s.rindex(")")]
+        f = s[s.rindex(")") + 2:].split()
+        out[int(tid)] = (name, (int(f[11]) + int(f[12])) / TICK)          # utime + stime
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=96)
+    ap.add_argument("--resident-only", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    w = bench.synth_weights()
+    eng = engine_mod.AdaINEngine(w[0], w[1], dev)
+    style = torch.from_numpy(synth.image(4, 1, 512, 512)).to(dev)
+    cache = {}
+    res = {}
+    for host in ((False,) if a.resident_only else (False, True)):
+        store = bench.FrameStore(4, a.frames, 0, a.frames, 1080, 1920, dev, host=host)
+        jobs.stylize_frames_sharded(eng, store, style, style_cache=cache, gather=False)          # warm
+        torch.cuda.synchronize()
+        t0, w0, p0 = threads(), time.perf_counter(), time.process_time()
+        _, info = jobs.stylize_frames_sharded(eng, store, style, style_cache=cache, gather=False)
+        torch.cuda.synchronize()
+        t1, wall, proc = threads(), time.perf_counter() - w0, time.process_time() - p0
+        rows, top = {}, []
+        for tid, (name, cpu) in t1.items():
+            d = cpu - t0.get(tid, (name, 0.0))[1]
+            key = "MainThread" if tid == os.getpid() else name
+            rows[key] = rows.get(key, 0.0) + d
+            top.append((round(d * 1e3 / a.frames, 3), key, tid - os.getpid()))
+        res["host_frames" if host else "resident_frames"] = {
+            "wall_s": round(wall, 3), "process_cpu_s": round(proc, 3), "launch_thread_cpu_s": round(info["host_cpu_s"], 3),
+            "cpu_ms_per_frame_by_thread": {k: round(v * 1e3 / a.frames, 3) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]) if v > 0},
+            "busiest_threads_ms_per_frame": sorted(top, reverse=True)[:4], "threads": len(t1)}
+        del store
+    print(json.dumps({"frames": a.frames, "what": "CPU per thread of a 1080p job", **res}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
