@@ -5,12 +5,20 @@ gfx950 kernels through the C ABI (include/adain_hip.h).  A GPU is required: ther
 Differences that are deliberate and invisible to callers:
   * weights are loaded from disk once per (path, mtime) and packed once, not on every call
     (the reference reloads 94 MB per call, test.py:183-184);
+  * the reference's batch callers call ``adain_inference`` once per frame / view with the SAME style (video/utils.py:341-350,
+    Style_3DGS/train.py:101) and every call re-encodes it (test.py:63 / :77): here the style's 2 x 512 channel statistics are kept
+    per (style file version | style image object, style_size, crop, encoder weights) and a plain RGB content image takes ONE
+    C-ABI call (``adain_stylize_u8``); the bytes written are those of the call-by-call path (``set_style_cache(False)`` runs
+    that path: tests compare the files);
   * torchvision / cv2 are not needed: ``test_transform`` and ``save_image`` are restated on PIL with
     torchvision 0.13 semantics (environment.yml:20);
   * the MiDaS depth estimator (test.py:84-116) is a pluggable provider (``set_depth_provider``):
     ``torch.hub`` needs the network; a caller-supplied callable or a precomputed depth map
     (``depth_map=`` keyword of ``adain_inference``) replaces it offline.
 """
+import time
+import weakref
+from collections import OrderedDict
 from pathlib import Path
 
 import numpy as np
@@ -129,10 +137,20 @@ def _load_into(module, path, tag):
 
 
 # ---------------------------------------------------------------------------------------------------------
+def _ready(module, device):
+    """``module.eval().to(device)`` without the walk over ~50 child modules when there is nothing to do (a per-call cost the
+    reference's callers pay once per frame)."""
+    if module.training:
+        module.eval()
+    if any(p.device != device for p in module.parameters()):
+        module.to(device)
+    return module
+
+
 def _singletons(device, vgg_str=None, decoder_str=None):
     """The module-level encoder / decoder (net.vgg, net.decoder) in eval mode on ``device`` with the checkpoints at the
     given paths loaded (once per file version; the reference re-reads both files on every call, test.py:183-184)."""
-    enc, dec = net.vgg.eval().to(device), net.decoder.eval().to(device)     # move first: .to() replaces the parameter storages
+    enc, dec = _ready(net.vgg, device), _ready(net.decoder, device)          # move first: .to() replaces the parameter storages
     if vgg_str is not None:
         _load_into(enc, vgg_str, "vgg")
     if decoder_str is not None:
@@ -146,6 +164,64 @@ def _as_batch(img, size, crop, device, rgb_only=False):
     return x[:, :3] if (rgb_only and x.shape[1] == 4) else x
 
 
+# ---------------------------------------------------------------------------------------------------------
+# style cache: what the encoder made of a style image, kept across calls with the same style
+# ---------------------------------------------------------------------------------------------------------
+_STYLE_CACHE_SIZE = 16
+_style_cache = OrderedDict()          # key -> (weakref to the style object | None, value)
+_style_cache_on = True
+STYLE_ENCODES = [0]                   # style images encoded by adain_inference / get_style_embeddings so far (tests count it)
+
+
+def set_style_cache(enabled):
+    """False: every ``adain_inference`` call re-encodes its style through the call-by-call path, as the reference does
+    (test.py:63 / :77); True (default): the style's statistics are kept across calls.  Returns the previous setting."""
+    global _style_cache_on
+    prev, _style_cache_on = _style_cache_on, bool(enabled)
+    return prev
+
+
+def clear_style_cache():
+    _style_cache.clear()
+
+
+def _style_key(style_img, what, style_size, crop, enc, device):
+    """Cache key of a style image: a file by (resolved path, mtime, size) - a rewritten file is another style -, an image object
+    by identity (guarded by a weak reference: a dead object's id may be reused), plus everything else the result depends on:
+    ``style_size``, ``crop``, the device and the encoder's parameter state (``load_state_dict`` / ``.to()`` / in-place edits
+    all change it).  None = not cacheable."""
+    params = (str(device),) + _param_state(enc)
+    if type(style_img) == str or isinstance(style_img, Path):
+        try:
+            p = Path(style_img).resolve()
+            st = p.stat()
+        except OSError:
+            return None, None
+        return (what, "file", str(p), st.st_mtime_ns, st.st_size, int(style_size), bool(crop), params), None
+    try:
+        ref = weakref.ref(style_img)
+    except TypeError:
+        return None, None
+    return (what, "object", id(style_img), getattr(style_img, "size", None), getattr(style_img, "mode", None), int(style_size), bool(crop),
+            params), ref
+
+
+def _cached_style(style_img, what, style_size, crop, enc, device, make):
+    """``make()`` once per style (see ``_style_key``); an LRU of ``_STYLE_CACHE_SIZE`` entries."""
+    key, ref = _style_key(style_img, what, style_size, crop, enc, device) if _style_cache_on else (None, None)
+    if key is not None:
+        hit = _style_cache.get(key)
+        if hit is not None and (hit[0] is None or hit[0]() is style_img):
+            _style_cache.move_to_end(key)
+            return hit[1]
+    value = make()
+    if key is not None:
+        _style_cache[key] = (ref, value)
+        while len(_style_cache) > _STYLE_CACHE_SIZE:
+            _style_cache.popitem(last=False)
+    return value
+
+
 def get_style_embeddings(
     style_img,
     vgg_str="Style_3DGS/AdaIN/models/vgg_normalised.pth",
@@ -153,10 +229,16 @@ def get_style_embeddings(
     crop=False,
 ):
     """relu4_1 features of the style image, [1,512,h,w] on the GPU (reference test.py:27-49; an alpha channel of
-    the style is dropped, :46-47).  No ``no_grad`` needed: the HIP path builds no autograd graph."""
+    the style is dropped, :46-47).  No ``no_grad`` needed: the HIP path builds no autograd graph.  The features of a style image
+    object are kept (``set_style_cache``); every call returns its own copy."""
     device = _device()
     enc, _ = _singletons(device, vgg_str=vgg_str)
-    return enc(_as_batch(style_img, style_size, crop, device, rgb_only=True))
+
+    def make():
+        STYLE_ENCODES[0] += 1
+        return enc(_as_batch(style_img, style_size, crop, device, rgb_only=True))
+
+    return _cached_style(style_img, "features", style_size, crop, enc, device, make).clone()
 
 
 def style_transfer(vgg, decoder, content, style, depth_map, alpha=1.0, offset=0.15, prominence=20):
@@ -273,10 +355,32 @@ def adain_inference(
     out_dir = Path(output)
     out_dir.mkdir(exist_ok=True, parents=True)
     enc, dec = _singletons(device, vgg_str, decoder_str)
+    target = out_dir / f"{file_name}{save_ext}"
+    T = _stage_timer
 
+    t0 = time.perf_counter()
     pil_content = Image.open(content_img) if type(content_img) == str else content_img
+    if _style_cache_on and not preserve_color and isinstance(enc, net.HipVGG) and isinstance(dec, net.HipDecoder):
+        # one style, many calls (video/utils.py:341-350, train.py:101): statistics from the cache, the frame in one C-ABI call
+        frame = test_transform_u8(content_size, crop)(pil_content)
+        T("open + resize content", t0)
+        if isinstance(frame, np.ndarray) and _mask_fits(content_mask):
+            assert 0.0 <= alpha <= 1.0                                   # test.py:55 / :75
+            if use_depth:
+                assert 0.0 <= depth_offset <= 1.0                        # test.py:56
+            t0 = time.perf_counter()
+            stats = _style_stats(style_img, style_size, crop, enc, device, drop_alpha=use_depth)
+            T("style statistics (cached after the first call)", t0)
+            if stats is not None:
+                _one_call(frame, stats, enc, dec, device, alpha, use_depth, depth_map, pil_content, depth_offset, depth_prominence, content_mask,
+                          target)
+                print(f"Image saved to {target}")
+                return target
+        content = _to_tensor(Image.fromarray(frame)) if isinstance(frame, np.ndarray) else frame
+    else:
+        content = test_transform(content_size, crop)(pil_content)
     pil_style = Image.open(str(style_img)) if type(style_img) == str else style_img
-    content = test_transform(content_size, crop)(pil_content)
+    STYLE_ENCODES[0] += 1
     style = test_transform(style_size, crop)(pil_style)
     if preserve_color:                       # CORAL runs on the host tensors, as in the reference (test.py:201-202)
         style = coral(style, content)
@@ -291,10 +395,98 @@ def adain_inference(
         result = composite_with_mask(content, result, content_mask)
     result = result[:, :3, :, :]             # an RGBA result keeps its colour planes only (test.py:240-241)
 
-    target = out_dir / f"{file_name}{save_ext}"
     save_image(result, str(target))
     print(f"Image saved to {target}")
     return target
+
+
+# ---- the one-call form of adain_inference ------------------------------------------------------------------------------------
+class _StageTimer:
+    """Off by default (one attribute test per stage).  ``bench.py --per-call`` switches it on to see where a call's time goes:
+    host stages by the host clock, the kernels by HIP events on the launch stream."""
+
+    def __init__(self):
+        self.on, self.host, self.events = False, {}, []
+
+    def __call__(self, stage, t0):
+        if self.on:
+            self.host[stage] = self.host.get(stage, 0.0) + time.perf_counter() - t0
+
+    def reset(self):
+        self.host, self.events = {}, []
+
+    def gpu_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.events)
+
+
+_stage_timer = _StageTimer()
+
+
+def _mask_fits(content_mask):
+    """The masks the reference's callers pass - [1,H,W] uint8 (localized_style_transfer.py:186), [3,H,W] bool (train.py:97) - and
+    their float forms; anything else takes the call-by-call path (and fails there exactly where the reference does)."""
+    if content_mask is None:
+        return True
+    m = content_mask
+    if not isinstance(m, (np.ndarray, torch.Tensor)) or m.ndim != 3 or m.shape[0] not in (1, 3):
+        return False
+    dt = str(m.dtype).replace("torch.", "")
+    return dt in ("uint8", "bool", "float32")
+
+
+def _style_stats(style_img, style_size, crop, enc, device, drop_alpha):
+    """(mean, std), each [1,512], of the style image's relu4_1 features (test.py:63 + function.py:4-12 / :77), computed once per
+    style (``_style_key``).  None when the transformed style is not a 3-channel image the encoder can take (4 channels with the
+    alpha blend: the reference fails in its first convolution; the call-by-call path reports it)."""
+    def make():
+        pil_style = Image.open(str(style_img)) if type(style_img) == str or isinstance(style_img, Path) else style_img
+        style = test_transform(style_size, crop)(pil_style)
+        if style.shape[0] == 4 and drop_alpha:
+            style = style[:3]                                             # test.py:60-61
+        if style.shape[0] != 3:
+            return None
+        STYLE_ENCODES[0] += 1
+        f = rt.encode(style.unsqueeze(0).to(device).contiguous(), enc.packed(device))
+        return rt.mean_std(f, True)
+
+    # an RGBA style gives other statistics on the depth path (alpha dropped) than on the alpha path (refused): part of the key
+    return _cached_style(style_img, ("stats", bool(drop_alpha)), style_size, crop, enc, device, make)
+
+
+def _one_call(frame, stats, enc, dec, device, alpha, use_depth, depth_map, pil_content, depth_offset, depth_prominence, content_mask, target):
+    """A resized RGB frame (uint8 HWC, host) -> the saved file: upload, ``adain_stylize_u8``, download, PIL save."""
+    T = _stage_timer
+    depth = None
+    if use_depth:
+        t0 = time.perf_counter()
+        proximity = depth_map if depth_map is not None else midas_depth_map_est(pil_content)
+        if not isinstance(proximity, torch.Tensor):
+            proximity = torch.as_tensor(np.asarray(proximity))
+        T("depth provider", t0)
+    t0 = time.perf_counter()
+    x = torch.from_numpy(frame).unsqueeze(0).to(device)
+    if use_depth:
+        depth = [proximity.to(device=device, dtype=torch.float32).contiguous()]
+    mask = None
+    if content_mask is not None:
+        m = content_mask if isinstance(content_mask, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(content_mask))
+        mask = m.to(device).unsqueeze(0)                                 # test.py:224-226 (the .float() happens in the kernel)
+    T("upload (frame, depth map, mask)", t0)
+    t0 = time.perf_counter()
+    if T.on:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    u8 = rt.stylize_u8(x, enc.packed(device), dec.packed(device), stats[0], stats[1], alpha, depth, depth_offset, depth_prominence, mask)
+    if T.on:
+        e1.record()
+        T.events.append((e0, e1))
+    T("launch (one C-ABI call)", t0)
+    t0 = time.perf_counter()
+    arr = u8[0].cpu().numpy()
+    T("wait for the kernels + download", t0)
+    t0 = time.perf_counter()
+    Image.fromarray(arr).save(str(target))
+    T("encode + write the file", t0)
 
 
 def composite_with_mask(content, output_img, content_mask):

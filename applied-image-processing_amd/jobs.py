@@ -250,6 +250,13 @@ class FrameFeeder:
         return all(t.shape == ts[0].shape and t.dtype == ts[0].dtype and not t.is_cuda for t in ts)
 
     def _run(self):
+        cpu0 = time.thread_time()
+        try:
+            self._run_inner()
+        finally:
+            self.stats["feeder_thread_cpu_s"] = time.thread_time() - cpu0
+
+    def _run_inner(self):
         try:
             if self.cuda:
                 torch.cuda.set_device(self.device)

@@ -627,6 +627,9 @@ def parse_args():
                          "of the timed region (no transport kernel beside the compute kernels); 'overlap' = one asynchronous gather per step")
     ap.add_argument("--sustain", type=float, default=2.0, help="single GPU, per-step mode: also run the same loop for at least this many seconds "
                     "after the timed region and report it as `sustained` (0 = skip)")
+    ap.add_argument("--per-call", choices=["video", "guide"], default=None,
+                    help="time the reference's unchanged caller loops (one adain_inference call per frame / view, files included) instead of the "
+                         "BASELINE step; --steps = calls (default 20)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="bare `--gpus N` launch: seconds after which the rank processes are stopped")
     ap.add_argument("--n1-value", type=float, default=0.0, help="--job: the 1-GPU value of the same job, to report efficiency_vs_n1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -844,9 +847,116 @@ def main_job(args, ctx):
     ctx.finish()
 
 
+def main_per_call(args, ctx):
+    """``--per-call video|guide``: what the reference's UNCHANGED callers get from one ``adain_inference`` call - the loop of
+    video/utils.py:341-350 (frame files in, ``content_size=256``, ``use_depth=True`` with a proximity map, JPEG out) or of
+    Style_3DGS/train.py:86-115 (PIL views in, ``content_size=512``, mask ``view > 0``, JPEG out) - with a per-stage breakdown, next
+    to the call-by-call path that re-encodes the style every time (as the reference does) and to the oracle on the host cores.
+    Not the BASELINE metric: a latency / calls-per-second line of its own (file I/O and PIL are inside, as they are for the caller)."""
+    import tempfile
+
+    from PIL import Image
+
+    from applied_image_processing_amd.AdaIN import test as T
+
+    mode, n = args.per_call, max(4, args.steps)
+    h, w = ((270, 480) if mode == "video" else (800, 800)) if not args.size else (args.size, args.size)     # the callers' own shapes
+    csize = 256 if mode == "video" else 512
+    root = tempfile.mkdtemp(prefix="adain_per_call_")
+    vgg_sd, dec_sd = synth.to_torch(synth.vgg_state_dict(0, full=True)), synth.to_torch(synth.decoder_state_dict(0))
+    torch.save(vgg_sd, os.path.join(root, "vgg.pth"))
+    torch.save(dec_sd, os.path.join(root, "dec.pth"))
+    ck = dict(vgg_str=os.path.join(root, "vgg.pth"), decoder_str=os.path.join(root, "dec.pth"))
+    frames = [(synth.image(7 + k, 1, h, w)[0].transpose(1, 2, 0) * 255).astype(np.uint8) for k in range(n)]
+    style_arr = (synth.image(4, 1, 700, 933)[0].transpose(1, 2, 0) * 255).astype(np.uint8)      # the sample style's size (SURVEY 8(c))
+    style_path = os.path.join(root, "style.jpg")
+    Image.fromarray(style_arr).save(style_path, quality=95)
+    os.makedirs(os.path.join(root, "frames"))
+    for k, a in enumerate(frames):
+        if mode == "guide":
+            a[synth.uniform01(2000 + k, h * w).reshape(h, w) < 0.3] = 0
+        Image.fromarray(a).save(os.path.join(root, "frames", f"frame_{k:04d}.jpg"), quality=95)
+    depth = [torch.from_numpy(synth.smooth_depth(6 + k, h, w)) for k in range(n)] if mode == "video" else None
+    style_obj = Image.open(style_path)
+    style_obj.load()
+
+    def call(k, out):
+        if mode == "video":
+            return T.adain_inference(os.path.join(root, "frames", f"frame_{k:04d}.jpg"), style_path, content_size=256, output=os.path.join(root, out),
+                                     file_name=f"frame_{k:04d}", depth_offset=0.30, depth_prominence=20, use_depth=True, depth_map=depth[k], **ck)
+        return T.adain_inference(content_img=Image.fromarray(frames[k]), style_img=style_obj, content_size=512, style_size=512,
+                                 content_mask=frames[k].transpose(2, 0, 1) > 0, output=os.path.join(root, out), file_name=f"view_{k:04d}", **ck)
+
+    def timed_loop(out, cache):
+        import contextlib
+        import io
+
+        T.clear_style_cache()
+        T.set_style_cache(cache)
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink):
+            for k in range(min(args.warmup, n)):
+                call(k, out)
+            torch.cuda.synchronize()
+            T._stage_timer.reset()
+            T._stage_timer.on = cache
+            c0, p0, t0 = time.thread_time(), time.process_time(), time.perf_counter()
+            paths = [call(k, out) for k in range(n)]
+            torch.cuda.synchronize()
+            dt, cpu, pcpu = time.perf_counter() - t0, time.thread_time() - c0, time.process_time() - p0
+        T._stage_timer.on = False
+        return dt, cpu, pcpu, paths
+
+    dt_plain, cpu_plain, _, plain = timed_loop("plain", False)
+    dt, cpu, pcpu, cached = timed_loop("cached", True)
+    stages = {k: round(v * 1e3 / n, 3) for k, v in T._stage_timer.host.items()}
+    gpu_ms = T._stage_timer.gpu_ms() / n
+    same = all(open(a, "rb").read() == open(b, "rb").read() for a, b in zip(cached, plain))
+    ch, cw = Image.open(cached[0]).size[::-1]
+    result = {"metric": f"adain_inference calls/s, the reference's {'video' if mode == 'video' else 'guide-view'} caller loop unchanged "
+                        "(file / PIL in, stylised JPEG file out)", "value": round(n / dt, 2), "unit": "calls/s", "n_gpus": 1, "steps": n,
+              "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / n, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": "f32", "data": "synthetic",
+              "config": {"workload": (f"{n} calls: {h}x{w} JPEG frame files, content_size=256 -> {ch}x{cw}, use_depth=True with a proximity map per frame, "
+                                      "one 933x700 style file resized to 512 (video/utils.py:341-350)" if mode == "video" else
+                                      f"{n} calls: {h}x{w} PIL views, content_size=512 -> {ch}x{cw}, mask = view > 0, one 933x700 PIL style resized to 512 "
+                                      "(Style_3DGS/train.py:86-115)") + ", fp32, seeded synthetic weights", "parallelism": "single GPU, one call at a time"},
+              "per_call": {"ms": round(dt * 1e3 / n, 3), "stages_ms": stages, "kernels_ms_by_hip_events": round(gpu_ms, 3),
+                           "calling_thread_cpu_ms": round(cpu * 1e3 / n, 3), "process_cpu_ms": round(pcpu * 1e3 / n, 3),
+                           "style_encodes": 1, "stylised_mpixels_per_s": round(n * ch * cw / 1e6 / dt, 2)},
+              "call_by_call_path": {"what": "set_style_cache(False): the style image is opened, resized and encoded in every call and the frame goes "
+                                            "through the separate C-ABI calls, as the reference does (test.py:190-247)", "ms": round(dt_plain * 1e3 / n, 3),
+                                    "calling_thread_cpu_ms": round(cpu_plain * 1e3 / n, 3), "files_identical_to_cached_path": bool(same)},
+              "speedup_vs_call_by_call": round(dt_plain / dt, 3)}
+    if not args.no_cpu:
+        from oracle import adain_oracle as O
+
+        torch.set_num_threads(int(os.environ.get("ADAIN_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16))))
+        ct = T.test_transform(csize, False)(Image.open(os.path.join(root, "frames", "frame_0000.jpg")) if mode == "video" else Image.fromarray(frames[0])).unsqueeze(0)
+        st = T.test_transform(512, False)(style_obj).unsqueeze(0)
+        times = []
+        with torch.no_grad():
+            for _ in range(3):
+                t0 = time.perf_counter()
+                if mode == "video":
+                    ref = O.quantize_u8(O.style_transfer(vgg_sd, dec_sd, ct, st, depth[0], 0.5, 0.30, 20))
+                else:
+                    ref = O.quantize_u8(O.mask_composite(ct, O.style_transfer_simple(vgg_sd, dec_sd, ct, st, 0.5), torch.from_numpy(frames[0].transpose(2, 0, 1) > 0)))
+                times.append(time.perf_counter() - t0)
+        result["cpu_baseline"] = {"value": round(1.0 / min(times), 3), "unit": "calls/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": f"3 forwards of call 0 through the oracle (tensor in, uint8 out; no file I/O), best {min(times) * 1e3:.0f} ms"}
+    import shutil
+
+    shutil.rmtree(root, ignore_errors=True)
+    print(json.dumps(result), flush=True)
+    ctx.finish()
+
+
 def main():
     args = parse_args()
     ctx = Ctx(args)
+    if args.per_call:
+        return main_per_call(args, ctx)
     if args.job:
         return main_job(args, ctx)
     world, rank, device, use_dist, transport, shared_gpu = ctx.world, ctx.rank, ctx.device, ctx.use_dist, ctx.transport, ctx.shared_gpu

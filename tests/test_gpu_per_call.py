@@ -1,0 +1,165 @@
+"""GPU tests of what the reference's UNCHANGED callers see (round 4): ``adain_inference`` called once per frame / view with the same
+style - video/utils.py:341-350 (files in, ``content_size=256``, ``use_depth=True``) and Style_3DGS/train.py:86-115 (PIL images in, a
+``view > 0`` mask).  The style is encoded once, every call is one C-ABI call, and the files are byte for byte those of the
+call-by-call path that re-encodes the style every time, as the reference does.  Run with ``-m gpu``."""
+import numpy as np
+import pytest
+import torch
+
+import applied_image_processing_amd.synth as synth
+from oracle import adain_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def u8img(seed, h, w, c=3):
+    return (synth.image(seed, 1, h, w, c=c)[0].transpose(1, 2, 0) * 255).astype(np.uint8)
+
+
+@pytest.fixture(scope="module")
+def ckpt(tmp_path_factory):
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    d = tmp_path_factory.mktemp("ckpt")
+    torch.save(synth.to_torch(synth.vgg_state_dict(0, full=True)), d / "vgg.pth")
+    torch.save(synth.to_torch(synth.decoder_state_dict(0)), d / "dec.pth")
+    return dict(vgg_str=str(d / "vgg.pth"), decoder_str=str(d / "dec.pth"))
+
+
+@pytest.fixture
+def t():
+    from applied_image_processing_amd.AdaIN import test as t
+
+    t.clear_style_cache()
+    prev = t.set_style_cache(True)
+    yield t
+    t.set_style_cache(prev)
+    t.clear_style_cache()
+
+
+def test_video_caller_loop_encodes_the_style_once_and_files_are_identical(t, ckpt, tmp_path):
+    """20 frames through the loop of video/utils.py:341-350."""
+    from PIL import Image
+
+    import applied_image_processing_amd.runtime as rt
+
+    (tmp_path / "frames").mkdir()
+    n = 20
+    for k in range(n):
+        Image.fromarray(u8img(900 + k, 270, 480)).save(tmp_path / "frames" / f"frame_{k:04d}.png")
+    style = tmp_path / "style.jpg"
+    Image.fromarray(u8img(950, 300, 400)).save(style, quality=95)
+    depth = [T(synth.smooth_depth(6 + k, 270, 480)) for k in range(n)]
+
+    def loop(out):
+        paths = []
+        for k in range(n):
+            frame = f"frame_{k:04d}.png"
+            paths.append(t.adain_inference(str(tmp_path / "frames" / frame), str(style), content_size=256, output=str(tmp_path / out),
+                                           file_name=frame.rsplit(".", 1)[0], depth_offset=0.30, depth_prominence=20, use_depth=True,
+                                           depth_map=depth[k], **ckpt))
+        return paths
+
+    # (a first call with another style_size: the checkpoints are loaded and packed before anything is counted)
+    t.adain_inference(str(tmp_path / "frames" / "frame_0000.png"), str(style), content_size=64, style_size=32, output=str(tmp_path / "warm"), **ckpt)
+    e0, c0 = t.STYLE_ENCODES[0], rt.ABI_CALLS[0]
+    cached = loop("cached")
+    assert t.STYLE_ENCODES[0] - e0 == 1                          # the style went through the encoder once ...
+    assert rt.ABI_CALLS[0] - c0 == n + 2                        # ... (encode + mean_std), and every frame is ONE C-ABI call
+    t.set_style_cache(False)
+    e0 = t.STYLE_ENCODES[0]
+    plain = loop("plain")
+    assert t.STYLE_ENCODES[0] - e0 == n                          # the call-by-call path re-encodes it per frame, as the reference does
+    for a, b in zip(cached, plain):
+        assert a.name == b.name and a.suffix == ".jpg" and a.read_bytes() == b.read_bytes()
+    assert Image.open(cached[0]).size == (456, 256)             # Resize(256) of 480 x 270 (video/utils.py:264)
+    # a rewritten style file is another style
+    t.set_style_cache(True)
+    t.adain_inference(str(tmp_path / "frames" / "frame_0000.png"), str(style), content_size=64, output=str(tmp_path / "o2"), **ckpt)
+    e0 = t.STYLE_ENCODES[0]
+    Image.fromarray(u8img(951, 300, 400)).save(style, quality=95)
+    t.adain_inference(str(tmp_path / "frames" / "frame_0000.png"), str(style), content_size=64, output=str(tmp_path / "o2"), **ckpt)
+    assert t.STYLE_ENCODES[0] - e0 == 1
+
+
+def test_guide_view_loop_with_masks_files_are_identical_and_close_to_the_oracle(t, ckpt, tmp_path, weights):
+    """Style_3DGS/train.py:86-115: PIL views, the same PIL style object, mask = view > 0 at the view's own size (the view is resized
+    to ``content_size``, the mask nearest-resized after it: test.py:222-236)."""
+    from PIL import Image
+
+    style = Image.fromarray(u8img(960, 200, 260))
+    views = []
+    for k in range(6):
+        a = u8img(970 + k, 160, 208)
+        a[T(synth.uniform01(2000 + k, 160 * 208).reshape(160, 208) < 0.3).numpy()] = 0
+        views.append(a)
+
+    def loop(out):
+        return [t.adain_inference(content_img=Image.fromarray(a), style_img=style, content_size=128, style_size=128,
+                                  content_mask=a.transpose(2, 0, 1) > 0, output=str(tmp_path / out), file_name=f"view_{k}", **ckpt)
+                for k, a in enumerate(views)]
+
+    e0 = t.STYLE_ENCODES[0]
+    cached = loop("cached")
+    assert t.STYLE_ENCODES[0] - e0 == 1
+    t.set_style_cache(False)
+    plain = loop("plain")
+    for a, b in zip(cached, plain):
+        assert a.read_bytes() == b.read_bytes()
+    # PNG (lossless) against the oracle on the same preprocessed tensors
+    t.set_style_cache(True)
+    p = t.adain_inference(content_img=Image.fromarray(views[0]), style_img=style, content_size=128, style_size=128,
+                          content_mask=views[0].transpose(2, 0, 1) > 0, output=str(tmp_path / "png"), file_name="v", save_ext=".png", **ckpt)
+    ct = t.test_transform(128, False)(Image.fromarray(views[0])).unsqueeze(0)
+    st = t.test_transform(128, False)(style).unsqueeze(0)
+    with torch.no_grad():
+        ref = O.quantize_u8(O.mask_composite(ct, O.style_transfer_simple(weights[0], weights[1], ct, st, 0.5), T(views[0].transpose(2, 0, 1) > 0)))[0].numpy()
+    got = np.asarray(Image.open(p))
+    assert got.shape == ref.shape and np.abs(got.astype(int) - ref.astype(int)).max() <= 1
+
+
+def test_style_cache_follows_the_weights_and_the_arguments(t, ckpt, tmp_path):
+    from PIL import Image
+
+    from applied_image_processing_amd.AdaIN import net
+
+    c, s = Image.fromarray(u8img(980, 64, 80)), Image.fromarray(u8img(981, 64, 80))
+    kw = dict(content_size=64, output=str(tmp_path / "o"), save_ext=".png", **ckpt)
+    e0 = t.STYLE_ENCODES[0]
+    a = t.adain_inference(c, s, style_size=48, file_name="a", **kw).read_bytes()
+    t.adain_inference(c, s, style_size=48, file_name="a2", **kw)
+    assert t.STYLE_ENCODES[0] - e0 == 1
+    t.adain_inference(c, s, style_size=32, file_name="b", **kw)                 # another style_size: another entry
+    assert t.STYLE_ENCODES[0] - e0 == 2
+    with torch.no_grad():                                                       # weights edited behind the wrapper's back: every entry is
+        net.vgg[2].bias.add_(0.01)                                              # stale; the wrapper reloads the checkpoint (the reference
+    b = t.adain_inference(c, s, style_size=48, file_name="c", **kw).read_bytes()    # reloads on EVERY call) and re-encodes the style
+    assert t.STYLE_ENCODES[0] - e0 == 3 and b == a
+    t.adain_inference(c, s, style_size=48, file_name="d", **kw)
+    assert t.STYLE_ENCODES[0] - e0 == 3
+    # preserve_color changes the style per content image (coral): never cached, call-by-call path
+    e0 = t.STYLE_ENCODES[0]
+    t.adain_inference(c, s, style_size=48, file_name="e", preserve_color=True, **kw)
+    t.adain_inference(c, s, style_size=48, file_name="f", preserve_color=True, **kw)
+    assert t.STYLE_ENCODES[0] - e0 == 2
+    # get_style_embeddings keeps a style object's features and hands out copies
+    e0 = t.STYLE_ENCODES[0]
+    f1 = t.get_style_embeddings(s, vgg_str=ckpt["vgg_str"], style_size=48)
+    f1.zero_()
+    f2 = t.get_style_embeddings(s, vgg_str=ckpt["vgg_str"], style_size=48)
+    assert t.STYLE_ENCODES[0] - e0 == 1 and float(f2.abs().sum()) > 0
+
+
+def test_rgba_and_grey_content_take_the_call_by_call_path(t, ckpt, tmp_path):
+    from PIL import Image
+
+    s = Image.fromarray(u8img(991, 64, 80))
+    rgba = Image.fromarray(u8img(990, 64, 80, c=4), "RGBA")
+    with pytest.raises(Exception):                     # a 4-channel content fails in the first convolution, here as in the reference
+        t.adain_inference(rgba, s, content_size=64, style_size=48, output=str(tmp_path / "o"), **ckpt)
+    p = t.adain_inference(Image.fromarray(u8img(992, 64, 80)), Image.fromarray(u8img(993, 64, 80, c=4), "RGBA"), content_size=64, style_size=48,
+                          use_depth=True, depth_map=T(synth.smooth_depth(5, 64, 80)), output=str(tmp_path / "o"), save_ext=".png", **ckpt)
+    assert p.exists()                                  # an RGBA style loses its alpha channel on the depth path (test.py:60-61)

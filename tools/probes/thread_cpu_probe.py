@@ -44,9 +44,13 @@ def main():
     ap.add_argument("--resident-only", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    born = {"before HIP": set(threads())}
     torch.cuda.set_device(0)
+    torch.zeros(1, device=dev)
+    born["HIP initialisation"] = set(threads())
     w = bench.synth_weights()
     eng = engine_mod.AdaINEngine(w[0], w[1], dev)
+    born["engine (first kernels)"] = set(threads())
     style = torch.from_numpy(synth.image(4, 1, 512, 512)).to(dev)
     cache = {}
     res = {}
@@ -54,6 +58,7 @@ def main():
         store = bench.FrameStore(4, a.frames, 0, a.frames, 1080, 1920, dev, host=host)
         jobs.stylize_frames_sharded(eng, store, style, style_cache=cache, gather=False)          # warm
         torch.cuda.synchronize()
+        born.setdefault("first job", set(threads()))
         t0, w0, p0 = threads(), time.perf_counter(), time.process_time()
         _, info = jobs.stylize_frames_sharded(eng, store, style, style_cache=cache, gather=False)
         torch.cuda.synchronize()
@@ -63,11 +68,13 @@ def main():
             d = cpu - t0.get(tid, (name, 0.0))[1]
             key = "MainThread" if tid == os.getpid() else name
             rows[key] = rows.get(key, 0.0) + d
-            top.append((round(d * 1e3 / a.frames, 3), key, tid - os.getpid()))
+            phase = next((ph for ph, ids in born.items() if tid in ids), "this job")
+            top.append((round(d * 1e3 / a.frames, 3), key, tid - os.getpid(), "born: " + phase))
         res["host_frames" if host else "resident_frames"] = {
             "wall_s": round(wall, 3), "process_cpu_s": round(proc, 3), "launch_thread_cpu_s": round(info["host_cpu_s"], 3),
             "cpu_ms_per_frame_by_thread": {k: round(v * 1e3 / a.frames, 3) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]) if v > 0},
-            "busiest_threads_ms_per_frame": sorted(top, reverse=True)[:4], "threads": len(t1)}
+            "busiest_threads_ms_per_frame": sorted(top, reverse=True)[:4], "threads": len(t1), "feeder": info["feeder"],
+            "cpu_of_threads_that_ended_with_the_job_s": round(proc - sum(rows.values()), 3)}
         del store
     print(json.dumps({"frames": a.frames, "what": "CPU per thread of a 1080p job", **res}), flush=True)
 
