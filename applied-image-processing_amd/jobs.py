@@ -298,10 +298,10 @@ class FrameFeeder:
                     with torch.cuda.stream(self.copy_stream):
                         if self.consumed[s] is not None:
                             self.copy_stream.wait_event(self.consumed[s])      # the kernels that read this slot have finished
-                        staged = False
+                        staged = False                                       # something was copied out of the slot's pinned buffers
+                        ordered = fetched is not None                        # `ready` must carry an ordering on to the consumer
                         if fetched is not None:
                             self.copy_stream.wait_event(fetched)
-                            staged = True                                    # `ready` carries the ordering on to the consumer
                         if isinstance(items, torch.Tensor):              # a ready block (device-resident store)
                             content = items
                         elif items[0].is_cuda:
@@ -325,10 +325,13 @@ class FrameFeeder:
                             else:                                        # masks of several sizes: one upload each, composited per frame
                                 mask = [m if m.is_cuda else self._upload(m) for m in mask]
                             staged = True
-                        if staged:
-                            ready = torch.cuda.Event()
+                        if staged or ordered:
+                            # blocking=True: a host wait on this event (the slot's next use, below) sleeps instead of spinning in
+                            # hipEventSynchronize - the feeder thread used to burn a whole core waiting for its uploads
+                            ready = torch.cuda.Event(blocking=True)
                             ready.record(self.copy_stream)
-                            self.h2d_done[s] = ready
+                            if staged:                                       # only pinned buffers need the host to wait before reuse
+                                self.h2d_done[s] = ready
                     self.stats["stage_s"] += time.perf_counter() - t3
                     if content is None:
                         content = items                                  # list of device tensors
@@ -447,7 +450,7 @@ class FileSink:
                 self.stream.wait_event(ready)
                 host.copy_(u8_block, non_blocking=True)
                 u8_block.record_stream(self.stream)
-                done = torch.cuda.Event()
+                done = torch.cuda.Event(blocking=True)      # the writer thread sleeps on it (a plain event would spin a core per writer)
                 done.record(self.stream)
             self.d2h_bytes += u8_block.numel()
 

@@ -6,7 +6,10 @@
 set -o pipefail
 tag="$1"; shift; parts="${*:-trace pmc configs all_kernels}"
 root="${GRAFT_REPO_ROOT:-$PWD}"; out="$root/gpurun_out"
-mkdir -p "$out"; cd /tmp; export TMPDIR=/tmp
+mkdir -p "$out"
+# the binary and sources on this box must be the ones of the manifest's commit (tools/profile_manifest.py --write, run before gpurun)
+python3 "$root/tools/profile_manifest.py" --check || exit 2
+cd /tmp; export TMPDIR=/tmp
 run() {   # name seconds program rocprof-args...   (BENCH_ARGS = the program's arguments)
   name="$1"; secs="$2"; prog="$3"; shift 3
   echo "=== $name"

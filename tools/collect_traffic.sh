@@ -4,7 +4,9 @@
 set -o pipefail
 tag="$1"; shift
 root="${GRAFT_REPO_ROOT:-$PWD}"; out="$root/gpurun_out"
-mkdir -p "$out"; cd /tmp; export TMPDIR=/tmp
+mkdir -p "$out"
+python3 "$root/tools/profile_manifest.py" --check || exit 2
+cd /tmp; export TMPDIR=/tmp
 for item in "$@"; do
   cfg="${item%%:*}"; batch=1; [ "$item" != "$cfg" ] && batch="${item#*:}"
   suffix=""; [ "$batch" != 1 ] && suffix="b$batch"

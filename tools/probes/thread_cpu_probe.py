@@ -76,6 +76,20 @@ def main():
             "busiest_threads_ms_per_frame": sorted(top, reverse=True)[:4], "threads": len(t1), "feeder": info["feeder"],
             "cpu_of_threads_that_ended_with_the_job_s": round(proc - sum(rows.values()), 3)}
         del store
+    # the same question for a bare kernel loop (no feeder, no second stream, no events): config-2 steps for about half a second
+    step = bench.Step(dev, config=2, engine=eng, weights=w)
+    step.run()
+    torch.cuda.synchronize()
+    t0, w0, p0 = threads(), time.perf_counter(), time.process_time()
+    for _ in range(150):
+        step.run()
+    enq = time.perf_counter() - w0
+    torch.cuda.synchronize()
+    t1, wall, proc = threads(), time.perf_counter() - w0, time.process_time() - p0
+    top = sorted(((round(cpu - t0.get(tid, (n_, 0.0))[1], 3), "MainThread" if tid == os.getpid() else n_, tid - os.getpid())
+                  for tid, (n_, cpu) in t1.items()), reverse=True)[:3]
+    res["bare_step_loop"] = {"wall_s": round(wall, 3), "enqueue_s": round(enq, 3), "process_cpu_s": round(proc, 3), "busiest_threads_cpu_s": top}
+    res["env"] = {k: v for k, v in os.environ.items() if k.split("_")[0] in ("HSA", "HIP", "ROC", "ROCR", "AMD", "GPU", "NCCL", "RCCL")}
     print(json.dumps({"frames": a.frames, "what": "CPU per thread of a 1080p job", **res}), flush=True)
 
 

@@ -26,7 +26,11 @@ import summarize_rocprof as sr  # noqa: E402
 
 rnd, btag, ptag = sys.argv[1:4]
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-HEAD = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+# the commit the profiles name = the code commit of the manifest they were collected under; refused if the product sources have moved since
+_st = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "profile_manifest.py"), "--stamp"], capture_output=True, text=True)
+if _st.returncode != 0:
+    sys.exit(_st.stderr.strip() or _st.stdout.strip())
+HEAD = _st.stdout.strip().split("\n")[-1]
 STAMP = f"(commit {HEAD}; 1 x MI355X box of the gpurun pool, ROCm 7.2, rocprofv3)"
 
 
