@@ -93,10 +93,20 @@ def as_frame(x):
 # for 512 resident workgroups); large ones lose to the L2-miss traffic that grows faster than the batch.
 AUTO_SUB_BATCH_PIXELS = 3.0e6
 MAX_AUTO_SUB_BATCH = 32
+MAX_QUEUED_BATCHES = 6             # sub-batches enqueued ahead of the device (stylize_frames_sharded)
 
 
 def auto_sub_batch(h, w):
     return int(max(1, min(MAX_AUTO_SUB_BATCH, round(AUTO_SUB_BATCH_PIXELS / max(1, h * w)))))
+
+
+def sleep_wait(event, period=2e-4):
+    """Host wait for a HIP event that SLEEPS.  ``event.synchronize()`` - and ``torch.cuda.synchronize`` - spin a core for as long as
+    the GPU is busy on this ROCm build, also for events created with ``blocking=True`` (measured: tools/probes/thread_cpu_probe.py:
+    the waiting thread's CPU time equals the wall time); with eight ranks on one host that is eight cores doing nothing.  Polling
+    ``query()`` with a short sleep costs nothing and at most ``period`` of latency, which none of the waits below is sensitive to."""
+    while not event.query():
+        time.sleep(period)
 
 
 class _Batch:
@@ -283,7 +293,7 @@ class FrameFeeder:
                         mask = torch.stack(mask)
                 else:
                     if self.h2d_done[s] is not None:
-                        self.h2d_done[s].synchronize()                   # the slot's previous uploads have left its pinned buffers
+                        sleep_wait(self.h2d_done[s])                     # the slot's previous uploads have left its pinned buffers
                     t3 = time.perf_counter()
                     self.stats["wait_h2d_s"] += t3 - t2
                     # device tensors handed over by the stores (a mask or depth map computed lazily in __getitem__, a frame
@@ -326,9 +336,7 @@ class FrameFeeder:
                                 mask = [m if m.is_cuda else self._upload(m) for m in mask]
                             staged = True
                         if staged or ordered:
-                            # blocking=True: a host wait on this event (the slot's next use, below) sleeps instead of spinning in
-                            # hipEventSynchronize - the feeder thread used to burn a whole core waiting for its uploads
-                            ready = torch.cuda.Event(blocking=True)
+                            ready = torch.cuda.Event()
                             ready.record(self.copy_stream)
                             if staged:                                       # only pinned buffers need the host to wait before reuse
                                 self.h2d_done[s] = ready
@@ -450,14 +458,14 @@ class FileSink:
                 self.stream.wait_event(ready)
                 host.copy_(u8_block, non_blocking=True)
                 u8_block.record_stream(self.stream)
-                done = torch.cuda.Event(blocking=True)      # the writer thread sleeps on it (a plain event would spin a core per writer)
+                done = torch.cuda.Event()
                 done.record(self.stream)
             self.d2h_bytes += u8_block.numel()
 
         def job():
             try:
                 if done is not None:
-                    done.synchronize()
+                    sleep_wait(done)                    # (a writer thread must not spin a core while the copy is on its way)
                 arr = host.numpy()
                 for k, p in enumerate(paths):
                     self._save(arr[k], p)
@@ -606,10 +614,17 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
                         copier.copy(host_out[r_lo + a:r_lo + a + cnts[r]], got[at:at + cnts[r]])
                 at += cnts[r]
 
+    # At most MAX_QUEUED_BATCHES sub-batches are queued on the device beyond the one that is running: enough that the GPU never
+    # waits for the host (a sub-batch is about three megapixels: >= 5 ms of kernels), few enough that this thread sleeps in
+    # sleep_wait instead of spinning inside hipLaunchKernel on a full HIP queue.
+    queued = []
+    on_gpu = dev.type == "cuda"
     try:
         cur_style = None
         stats = style_cache if style_cache is not None else {}
         for batch in feeder:
+            if on_gpu and len(queued) >= MAX_QUEUED_BATCHES:
+                sleep_wait(queued.pop(0))
             i, j = batch.i, batch.j
             if style_of[i] != cur_style:
                 cur_style = style_of[i]
@@ -635,6 +650,10 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
                     out = engine.composite(content, out, batch.mask.to(dev).float())
                 u8 = engine.to_u8(out)
             feeder.release(batch)
+            if on_gpu:
+                e = torch.cuda.Event()
+                e.record(torch.cuda.current_stream(dev))
+                queued.append(e)
             if post is not None:
                 u8 = post(u8)
             shapes.add(tuple(u8.shape[1:]))
@@ -681,6 +700,10 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
     info["abi_calls"] = getattr(engine, "abi_calls", lambda: 0)() - abi0
 
     def finish_times(m2=None):
+        if on_gpu:                          # sleep until the device has finished this job's work, then the (now immediate) synchronisations
+            e = torch.cuda.Event()
+            e.record(torch.cuda.current_stream(dev))
+            sleep_wait(e)
         if copier is not None:
             copier.finish()
             info["d2h_bytes"] = copier.bytes
