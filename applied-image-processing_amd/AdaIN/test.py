@@ -464,7 +464,7 @@ def _one_call(frame, stats, enc, dec, device, alpha, use_depth, depth_map, pil_c
             proximity = torch.as_tensor(np.asarray(proximity))
         T("depth provider", t0)
     t0 = time.perf_counter()
-    x = torch.from_numpy(frame).unsqueeze(0).to(device)
+    x = torch.from_numpy(frame if frame.flags.writeable else frame.copy()).unsqueeze(0).to(device)     # (np.asarray of a PIL image is read-only)
     if use_depth:
         depth = [proximity.to(device=device, dtype=torch.float32).contiguous()]
     mask = None

@@ -469,6 +469,8 @@ def measure_roofline(step, reps):
     executed = algorithmic * EXECUTED
     layers = [{"gflop": f / 1e9, "ms": t / reps, "tflops": f / (t / reps * 1e-3) / 1e12} for f, t in zip(flops, per_layer)]
     traffic, traffic_src = load_pmc_traffic(f"config{step.config}_batch{step.batch}")
+    if (step.h, step.w) != SIZES[step.config] or (step.hs, step.ws) != (512, 512):
+        traffic, traffic_src = None, None          # the committed counter passes are of the config's own sizes
     roof = {
         "bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -104,5 +104,34 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < n8; ++i) { sum += h8[i]; fnv = (fnv ^ h8[i]) * 1099511628211ull; }
     printf("c_abi_smoke: abi %d, %dx%d content, %dx%d style -> %dx%d image, sum %llu, fnv %016llx\n", adain_abi_version(), H, W,
            Hs, Ws, 8 * hc, 8 * wc, (unsigned long long)sum, (unsigned long long)fnv);
+
+    /* the same frame as a DECODED uint8 frame with a mask (byte > 96), through the one-call entry point: what a video / guide-view
+     * loop does per frame once the style statistics exist (stats + 1024 / + 1536 above) */
+    const size_t px = (size_t)H * W;
+    uint8_t* hf = (uint8_t*)malloc(px * 3);
+    uint8_t* hm = (uint8_t*)malloc(px * 3);
+    for (size_t p = 0; p < px; ++p)
+        for (int c = 0; c < 3; ++c) {
+            hf[p * 3 + c] = (uint8_t)((hashf(1, (uint32_t)(c * px + p)) + 0.5f) * 255.0f);     /* HWC bytes of the float frame above */
+            hm[c * px + p] = hf[p * 3 + c] > 96;                                              /* mask [1][3][H][W] */
+        }
+    uint8_t *df, *dm, *d8;
+    CK(hipMalloc((void**)&df, px * 3));
+    CK(hipMalloc((void**)&dm, px * 3));
+    CK(hipMalloc((void**)&d8, px * 3));
+    CK(hipMemcpy(df, hf, px * 3, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dm, hm, px * 3, hipMemcpyHostToDevice));
+    int oh, ow;
+    adain_stylize_u8_out_size(H, W, 1, &oh, &ow);
+    const size_t sb = adain_stylize_u8_workspace_bytes(1, H, W, 0, 1, 3, H, W, 0);
+    void* sws;
+    CK(hipMalloc(&sws, sb));
+    AD(adain_stylize_u8(df, 1, H, W, pe, pd, stats + 1024, stats + 1536, 0.5f, 0.5f, NULL, NULL, NULL, 0.f, 0.f, dm, 0, 1, 3, H, W, d8, sws, sb, s));
+    CK(hipStreamSynchronize(s));
+    uint8_t* o8 = (uint8_t*)malloc(px * 3);
+    CK(hipMemcpy(o8, d8, px * 3, hipMemcpyDeviceToHost));
+    sum = 0; fnv = 1469598103934665603ull;
+    for (size_t i = 0; i < px * 3; ++i) { sum += o8[i]; fnv = (fnv ^ o8[i]) * 1099511628211ull; }
+    printf("c_abi_smoke: adain_stylize_u8 masked frame -> %dx%d, sum %llu, fnv %016llx\n", oh, ow, (unsigned long long)sum, (unsigned long long)fnv);
     return 0;
 }

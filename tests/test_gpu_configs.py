@@ -199,3 +199,46 @@ def test_c_abi_from_plain_c(tmp_path):
     for b in u8.tolist():
         fnv = ((fnv ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert m.group(4) == f"{fnv:016x}"
+    # ... and the one-call entry point on the same frame as decoded bytes with a mask
+    m2 = re.search(r"adain_stylize_u8 masked frame -> (\d+)x(\d+), sum (\d+), fnv ([0-9a-f]{16})", r.stdout)
+    assert m2, r.stdout
+    frame = ((_hashf(1, 3 * H * W) + np.float32(0.5)) * np.float32(255.0)).astype(np.uint8).reshape(3, H, W)
+    fu8 = T(frame.transpose(1, 2, 0)).cuda().unsqueeze(0)
+    got = e.stylize_u8(fu8, alpha=0.5, masks=T(frame > 96).cuda().unsqueeze(0)).cpu().numpy().reshape(-1)
+    assert (int(m2.group(1)), int(m2.group(2))) == (H, W) and int(m2.group(3)) == int(got.astype(np.uint64).sum())
+    fnv = 1469598103934665603
+    for b in got.tolist():
+        fnv = ((fnv ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert m2.group(4) == f"{fnv:016x}"
+
+
+def _bench(args, timeout=240):
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_front_door_starts_its_own_ranks():
+    """``python bench.py --gpus 2`` typed bare, as the driver types it: two fresh rank processes (here they share the one GPU:
+    ``--rehearse``, labelled), ONE JSON line from rank 0, exit status 0; the default gather mode is the end-of-region gather and
+    the line shows what the transport saw.  Without ``--rehearse`` two ranks on one GPU are refused with a clear message."""
+    import json
+
+    r = _bench(["--gpus", "2", "--rehearse", "--no-cpu", "--no-secondary", "--steps", "3", "--warmup", "1", "--size", "256"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["rehearsal"]["ranks_share_a_gpu"]
+    assert d["gather"]["mode"] == "end" and d["gather"]["gathers_in_timed_region"] == 1
+    assert d["ranks"]["world"] == 2 and d["ranks"]["allreduce_of_ones"] == 2 and len(d["ranks"]["devices"]) == 2
+    assert d["ranks"]["launcher"] == "bench.py self-launch" and len({x["pid"] for x in d["ranks"]["devices"]}) == 2
+    assert [p["rank"] for p in d["per_rank"]] == [0, 1] and all(p["compute_ms"] > 0 for p in d["per_rank"])
+    if __import__("torch").cuda.device_count() < 2:
+        r = _bench(["--gpus", "2", "--no-cpu", "--steps", "3"], timeout=120)
+        assert r.returncode != 0 and "2 ranks, one per GPU" in (r.stderr + r.stdout)

@@ -187,3 +187,18 @@ def test_sharding_helpers_without_a_process_group():
     assert sh.agree_geometry(True, {(4, 6, 3)}) == (True, (4, 6, 3), True)
     assert sh.agree_geometry(True, {(4, 6, 3), (4, 8, 3)})[2] is False
     assert sh.agree_geometry(False, set()) == (False, None, True)
+
+
+def test_bench_front_door_refuses_more_ranks_than_gpus_before_any_work():
+    """``python bench.py --gpus N`` (no torchrun typed) on a box with fewer than N GPUs: a clear message and a non-zero status from the
+    launcher itself, before any rank is started (here: no GPU at all)."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 2 means 2 ranks, one per GPU" in r.stderr and "{" not in r.stdout
