@@ -75,8 +75,16 @@ for rep in range(3):
     flows = T(np.stack([synth.uniform_sym(14 + i, (2, 1080, 1920), 2.0) for i in range(3)])).to(dev)
     tb = temporal_blend(v, flows, 0.7)                       # warp_blend_u8_rgb4_kernel
     wb = rt.warp_blend_u8(u8(15, 1, 40, 56, c=1)[0], u8(16, 1, 40, 56, c=1)[0], T(synth.uniform_sym(17, (2, 40, 56), 2.0)).to(dev), 0.7)
+    # one sub-batch in one call: the fused composite + quantise tail (uint8 / float masks, vector and generic forms) and the general tail
+    eng.stylize_u8(frames, 0.5, masks=(frames > 0).permute(0, 3, 1, 2).contiguous())          # composite_quantize_u8_kernel<uint8_t, true>
+    eng.stylize_u8(frames, 0.5, masks=(f32 > 0.3).float())                                     # composite_quantize_u8_kernel<float, true>
+    small_u8 = u8(18, 1, 72, 104)
+    eng.stylize_u8(small_u8, 0.5, masks=(small_u8[:, ::2, ::2] > 40).permute(0, 3, 1, 2).contiguous())    # mask_to_f32 + the resize / composite chain
+    odd_u8 = u8(19, 1, 45, 67)
+    eng.stylize_u8(odd_u8, 0.5, masks=(odd_u8 > 40).permute(0, 3, 1, 2).contiguous())
+    eng.stylize_u8(frames, depth_maps=[depth[:600, :800].contiguous(), depth], offset=0.3)     # depth-aware form
     torch.cuda.synchronize()
-called += ["adain_encode_multi", "adain_encode_u8", "adain_encode", "adain_decode", "adain_mean_std", "adain_blend_alpha", "adain_blend_pmap",
+called += ["adain_stylize_u8", "adain_encode_multi", "adain_encode_u8", "adain_encode", "adain_decode", "adain_mean_std", "adain_blend_alpha", "adain_blend_pmap",
            "adain_strength_map", "adain_u8_to_f32", "adain_resize_bilinear", "adain_resize_nearest", "adain_mask_composite", "adain_quantize_u8",
            "adain_resize_area_u8", "adain_warp_blend_u8", "adain_nhwc_to_nchw", "adain_nchw_to_nhwc"]
 # the single-layer entry point (BIG descriptors are exercised by tests/test_gpu_parity.py::test_conv_tensors_above_two_gib)

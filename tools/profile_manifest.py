@@ -21,7 +21,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MANIFEST = os.path.join(ROOT, "tools", ".profile_manifest.json")
-CODE_PATHS = ["applied-image-processing_amd", "include", "bench.py", "tools/all_kernels.py"]
+CODE_PATHS = ["applied-image-processing_amd", "include", "bench.py"]
 LIB = os.path.join(ROOT, "applied-image-processing_amd", "libadain_hip.so")
 
 
@@ -36,7 +36,7 @@ def sha(path):
 def sources():
     out = []
     for pat in ("applied-image-processing_amd/csrc/*", "applied-image-processing_amd/*.py", "applied-image-processing_amd/AdaIN/*.py", "include/*.h",
-                "bench.py", "tools/all_kernels.py"):
+                "bench.py"):
         out += sorted(glob.glob(os.path.join(ROOT, pat)))
     return [p for p in out if os.path.isfile(p)]
 
