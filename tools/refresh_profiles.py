@@ -57,7 +57,9 @@ def counters(d):
 
 # ---- bench lines ------------------------------------------------------------------------------------------------------------------
 lines = {"c2": "config2", "c2_pcie": "config2_pcie", "c3": "config3", "c4": "config4", "c5": "config5", "c4job": "config4_job",
-         "c5job": "config5_job", "c2_ws1": "config2_ws1_rccl", "c4job_ws1": "config4_job_ws1_rccl", "c5job_ws1": "config5_job_ws1_rccl"}
+         "c5job": "config5_job", "c2_ws1": "config2_ws1_rccl", "c4job_ws1": "config4_job_ws1_rccl", "c5job_ws1": "config5_job_ws1_rccl",
+         "c2_ws1_overlap": "config2_ws1_rccl_gather_overlap", "c2_style1024": "config2_style1024", "c4_depth_job": "config4_depth_job",
+         "pc_video": "per_call_video", "pc_guide": "per_call_guide", "reh2_end": "rehearsal_2ranks_one_gpu", "reh3_job": "rehearsal_3ranks_one_gpu_job5_chunked"}
 bench = {}
 for src, dst in lines.items():
     path = os.path.join(G, f"{btag}_{src}.log")
@@ -80,7 +82,7 @@ u = bench.get("c2", b)
 open(os.path.join(P, f"{rnd}_kernel_trace.md"), "w").write(
     f"# {rnd} — rocprofv3 kernel trace of `bench.py --no-cpu --steps 10 --warmup 2` (config 2, with the 1080p pixel-kernel leg) {STAMP}\n\n"
     "`tools/collect_profiles.sh <tag> trace`: `cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d … -- python3 bench.py --no-cpu "
-    "--steps 10 --warmup 2` (2 warm-up + 10 timed + 7 event-instrumented steps, then the frame-sized pixel kernels of the video / guide\n"
+    "--steps 10 --warmup 2` (2 warm-up + 10 timed steps, the `sustained` leg - the same loop for two more seconds -, 7 event-instrumented steps, then the frame-sized pixel kernels of the video / guide\n"
     "post-pass on 8 x 1080p: `resize_area*`, `warp_blend_u8*`, `quantize_u8*`, `mask_composite`, `resize_*`).\n"
     f"bench line of the same (profiled) run: {b['value']:.2f} Mpixels/s, {b['ms_per_step']:.3f} ms/step, roofline.avg_launch_ms "
     f"{b['roofline']['avg_launch_ms']:.4f} (HIP events); unprofiled run of the same binary: profiles/{rnd}_bench_config2.json "
