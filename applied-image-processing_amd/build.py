@@ -40,8 +40,9 @@ def _newer(target, deps):
 
 
 def build(force=False, verbose=False, diag=False):
-    """Builds the product library; ``diag=True`` builds ``libadain_hip_diag.so`` instead (same sources with -DADAIN_DIAG: the
-    environment tuning switches and the stamp / timing-only kernel variants used by tools/; load it with ADAIN_HIP_LIB=...)."""
+    """Builds the product library; ``diag=True`` builds ``libadain_hip_diag.so`` instead (the same sources with -DADAIN_DIAG plus the
+    older kernel families: environment tuning switches, stamp / timing-only variants used by tools/).  A process loads it explicitly
+    with ``runtime.use_library(runtime.DIAG_LIB_PATH)`` - nothing in the environment selects it."""
     objdir = os.path.join(PKG, "build_diag" if diag else "build")
     os.makedirs(objdir, exist_ok=True)
     lib = DIAG_LIB if diag else LIB

@@ -311,6 +311,35 @@ def test_localized_pipeline_end_to_end(rt, weights, tmp_path):
         L.run_localized_style_transfer(str(tmp_path / "c.png"), str(tmp_path / "s.png"), output_path=str(tmp_path / "o"))
 
 
+def test_run_semantic_segm_cli_equals_the_function_call(rt, weights, tmp_path):
+    """The CLI of the reference's Style_3DGS/run_semantic_segm.py (:12-44: --content --style --output --file_name --use_depth) with a
+    precomputed mask and proximity map in place of the two network downloads: same files as calling the pipeline directly."""
+    from PIL import Image
+
+    from applied_image_processing_amd import localized as L
+    from applied_image_processing_amd import run_semantic_segm as cli
+
+    torch.save(synth.to_torch(synth.vgg_state_dict(0, full=True)), tmp_path / "vgg.pth")
+    torch.save(weights[1], tmp_path / "dec.pth")
+    Image.fromarray(u8img(440, 72, 104)).save(tmp_path / "c.png")
+    Image.fromarray(u8img(441, 64, 64)).save(tmp_path / "s.png")
+    yy, xx = np.mgrid[:72, :104]
+    bg = (((yy - 36) ** 2 + (xx - 52) ** 2) > 400).astype(np.uint8)
+    np.save(tmp_path / "mask.npy", bg)                                              # [H,W]: the CLI adds the channel axis
+    np.save(tmp_path / "depth.npy", synth.smooth_depth(7, 72, 104))
+    ck = ["--vgg", str(tmp_path / "vgg.pth"), "--decoder", str(tmp_path / "dec.pth")]
+    p = cli.main(["--content", str(tmp_path / "c.png"), "--style", str(tmp_path / "s.png"), "--output", str(tmp_path / "cli"), "--use_depth",
+                  "--mask_npy", str(tmp_path / "mask.npy"), "--depth_npy", str(tmp_path / "depth.npy")] + ck)
+    q = L.run_localized_style_transfer(str(tmp_path / "c.png"), str(tmp_path / "s.png"), output_path=str(tmp_path / "fn"), file_name="stylized",
+                                       use_depth=True, background_mask=bg[None], depth_map=T(synth.smooth_depth(7, 72, 104)),
+                                       vgg_str=str(tmp_path / "vgg.pth"), decoder_str=str(tmp_path / "dec.pth"))
+    assert p == f"{tmp_path / 'cli'}/localized_style_transfer_result.jpg" and (tmp_path / "cli" / "stylized.jpg").exists()     # reference naming
+    assert open(p, "rb").read() == open(q, "rb").read()
+    assert (tmp_path / "cli" / "stylized.jpg").read_bytes() == (tmp_path / "fn" / "stylized.jpg").read_bytes()
+    with pytest.raises(SystemExit):
+        cli.main(["--style", "s.png"])                                              # --content is required, as in the reference
+
+
 def test_checkpoint_cache_notices_foreign_weights(rt, weights, tmp_path):
     """adain_inference caches the loaded checkpoints per file version; weights written into the module singletons by anyone
     else in between must not be mistaken for the file's (results must not depend on call order)."""
