@@ -120,6 +120,26 @@ def test_full_size_view_with_mask_against_oracle(engine, weights):
     assert d.max() <= 1 and float((d > 0).float().mean()) < 1e-3
 
 
+def test_random_shapes_depth_and_mask_together(engine):
+    """Seeded random sub-batches: frame sizes on and off the 8-pixel grid (both Winograd tile geometries, fused and general tails),
+    1-3 frames, depth maps of their own sizes TOGETHER with masks of every dtype / channel count / batch form."""
+    g = np.random.default_rng(20260404)
+    for case in range(14):
+        n = int(g.integers(1, 4))
+        h, w = (int(g.integers(2, 20)) * 8, int(g.integers(2, 26)) * 8) if case % 2 == 0 else (int(g.integers(17, 150)), int(g.integers(17, 200)))
+        x = u8frames(1000 + 10 * case, n, h, w).cuda()
+        depth = None
+        if case % 3 != 2:
+            depth = [T(synth.smooth_depth(40 + case + i, int(g.integers(9, 90)), int(g.integers(9, 90)))).cuda() for i in range(n)]
+        mh, mw = (h, w) if case % 4 < 2 else (int(g.integers(5, 60)), int(g.integers(5, 60)))
+        mn, mc = (1 if case % 5 == 0 else n), (1 if case % 2 else 3)
+        m = T(g.random((mn, mc, mh, mw)) > 0.45)
+        m = [m, m.to(torch.uint8), m.float() * T(g.random((mn, mc, mh, mw)).astype(np.float32))][case % 3].cuda()
+        got = engine.stylize_u8(x, alpha=0.4, depth_maps=depth, offset=0.25, prominence=12, masks=m)
+        want = separate_calls(engine, x, 0.4, depth=depth, offset=0.25, prominence=12, masks=m)
+        assert got.shape == (n, h, w, 3) and torch.equal(got, want), (case, n, h, w, mn, mc, mh, mw, str(m.dtype))
+
+
 def test_bad_arguments_raise(rt, engine):
     x = u8frames(790, 1, 32, 32).cuda()
     with pytest.raises(rt.AdainHipError):
