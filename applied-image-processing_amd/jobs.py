@@ -404,7 +404,9 @@ class HostCopier:
 
     def finish(self):
         if self.cuda:
-            self.stream.synchronize()
+            done = torch.cuda.Event()
+            done.record(self.stream)
+            sleep_wait(done)
 
 
 class FileSink:
@@ -937,6 +939,8 @@ def run_timed_steps(step, steps, warmup, *, barrier, block_shape, device, mode="
     the last gathered frame on this rank's stream (mode "overlap": the gathers of all but the last two steps lie inside compute_ms)."""
     if mode not in GATHER_MODES:
         raise ValueError(f"gather mode must be one of {GATHER_MODES}, got {mode!r}")
+    if steps < 1 or warmup < 0:
+        raise ValueError(f"run_timed_steps: steps must be >= 1 and warmup >= 0, got {steps} / {warmup}")
     rank, world = _rank_world(group)
     gathering = bool(gather) and sh.dist_on()
     b = int(block_shape[0])

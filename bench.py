@@ -100,7 +100,7 @@ def self_launch():
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), ADAIN_SELF_LAUNCHED="1")
+                   MASTER_PORT=str(port), ADAIN_SELF_LAUNCHED=str(os.getpid()))
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True,
                                       stdout=None if r == 0 else sys.stderr))
@@ -145,8 +145,25 @@ def self_launch():
     raise SystemExit(worst)
 
 
+def watch_launcher():
+    """A rank started by ``self_launch`` must not outlive it: if the launcher dies without stopping its ranks (SIGKILL), a daemon
+    thread notices the re-parenting within a second and ends this process, so no orphan keeps a GPU busy."""
+    pid = os.environ.get("ADAIN_SELF_LAUNCHED", "")
+    if not pid.isdigit():
+        return
+    import threading
+
+    def watch():
+        while os.getppid() == int(pid):
+            time.sleep(1.0)
+        os._exit(70)
+
+    threading.Thread(target=watch, name="adain-launcher-watch", daemon=True).start()
+
+
 if __name__ == "__main__":
     self_launch()
+    watch_launcher()
 
 import numpy as np
 import torch
