@@ -396,6 +396,7 @@ int adain_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, adain_
 struct StylizePlan {
     int hc, wc, H8, W8;               // relu4_1 map; decoder output size (8hc x 8wc)
     int identity;                     // mask, decoder output and frame share one size: the fused composite + quantise tail
+    int mask_only;                    // decoder output and frame share one size, the mask has another: the same tail sampling the mask
     size_t conv, feat, stat, stats_ws, pmap, pmap_ws, img, content, mask_f, mask_r, sty_r, comp, total;   // floats (conv / *_ws: bytes / 4)
 };
 static StylizePlan stylize_plan(int n, int h, int w, int use_depth, int mask_n, int mask_c, int mask_h, int mask_w, int mask_is_float) {
@@ -414,7 +415,8 @@ static StylizePlan stylize_plan(int n, int h, int w, int use_depth, int mask_n, 
     p.img = align64((size_t)n * 3 * p.H8 * p.W8);
     if (mask_n > 0) {
         p.identity = mask_h == h && mask_w == w && p.H8 == h && p.W8 == w;
-        if (!p.identity) {
+        p.mask_only = !p.identity && p.H8 == h && p.W8 == w;
+        if (!p.identity && !p.mask_only) {
             p.content = align64((size_t)n * 3 * h * w);
             p.mask_f = mask_is_float ? 0 : align64((size_t)mask_n * mask_c * mask_h * mask_w);
             p.mask_r = (mask_h == h && mask_w == w) ? 0 : align64((size_t)mask_n * mask_c * h * w);
@@ -490,6 +492,8 @@ int adain_stylize_u8(const uint8_t* frames, int n, int h, int w, const float* en
     if (mask_n == 0) return launch_quantize_u8(img, out_u8, n, 3, p.H8, p.W8, s);                                // test.py:243-244
     if (p.identity)         // both F.interpolate calls of test.py:227-234 are identities: composite + quantise in one pass
         return launch_composite_quantize_u8(frames, img, mask, mask_is_float, mask_c, mask_n, out_u8, n, h * w, s);
+    if (p.mask_only)        // only the mask needs its nearest resize: an index map, sampled in place by the same fused tail
+        return launch_composite_quantize_u8_nearest(frames, img, mask, mask_is_float, mask_c, mask_n, mask_h, mask_w, out_u8, n, h, w, s);
     // the general composite (test.py:222-236): mask.float() -> nearest to the frame size; output -> bilinear to the frame size
     RET_IF(launch_u8_to_f32(frames, content_f, n, 3, h, w, s));
     const float* m = (const float*)mask;

@@ -123,6 +123,8 @@ int launch_u8_to_f32(const uint8_t* in_nhwc, float* out_nchw, int n, int c, int 
 int launch_resize_area_u8(const uint8_t* in, uint8_t* out, int n, int hi, int wi, int c, int ho, int wo, hipStream_t s);
 int launch_composite_quantize_u8(const uint8_t* content_nhwc, const float* stylized_nchw, const void* mask, int mask_is_float,
                                  int mask_c, int mask_n, uint8_t* out_nhwc, int n, int hw, hipStream_t s);
+int launch_composite_quantize_u8_nearest(const uint8_t* content_nhwc, const float* stylized_nchw, const void* mask, int mask_is_float,
+                                         int mask_c, int mask_n, int mh, int mw, uint8_t* out_nhwc, int n, int h, int w, hipStream_t s);
 int launch_mask_to_f32(const uint8_t* in, float* out, size_t total, hipStream_t s);
 int launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, hipStream_t s);

@@ -447,6 +447,75 @@ int launch_composite_quantize_u8(const uint8_t* content, const float* stylized, 
     return check_launch("composite_quantize_u8");
 }
 
+// The same tail when only the MASK has another size than the frame (the 3DGS guide loop: the view is resized to content_size, its
+// mask arrives at the view's own size, Style_3DGS/train.py:97-101): F.interpolate(mask.float(), size, mode="nearest") is an index
+// map - source row min(floor(oy * mh / h), mh - 1), column likewise, in float as ATen computes it (resize_nearest_kernel above) -
+// so the mask is sampled in place and the five passes (u8_to_f32, mask_to_f32, resize_nearest, mask_composite, quantize_u8) run
+// as one.  A thread owns 4 consecutive pixels of row oy (blockIdx.y * 4 + threadIdx.y) of image blockIdx.z.
+template <typename MaskT>
+__global__ __launch_bounds__(256) void composite_quantize_u8_nearest_kernel(const uint8_t* __restrict__ content, const float* __restrict__ sty,
+                                                                            const MaskT* __restrict__ mask, int mask_c, int mask_n, int mh,
+                                                                            int mw, uint8_t* __restrict__ out, int h, int w, int vec) {
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4, oy = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || oy >= h) return;
+    const unsigned img = blockIdx.z;
+    const float sy = (float)mh / (float)h, sx = (float)mw / (float)w;
+    const int my = min((int)floorf((float)oy * sy), mh - 1);
+    const size_t mplane = (size_t)mh * mw;
+    const MaskT* __restrict__ mrow = mask + (size_t)(mask_n == 1 ? 0u : img) * mask_c * mplane + (size_t)my * mw;
+    const size_t mstep = mask_c == 1 ? 0 : mplane;
+    const size_t hw = (size_t)h * w, pix0 = (size_t)oy * w + x;
+    const float* __restrict__ sp = sty + (size_t)img * 3 * hw + pix0;
+    const uint8_t* __restrict__ cp = content + ((size_t)img * hw + pix0) * 3;
+    uint8_t* __restrict__ op = out + ((size_t)img * hw + pix0) * 3;
+    const int np = min(4, w - x);
+    int mx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mx[k] = min((int)floorf((float)min(x + k, w - 1) * sx), mw - 1);
+    unsigned by[12];
+    if (vec) {            // w % 4 == 0: the thread's 12 content bytes are one aligned 96-bit load, its stylised values three b128
+        using u32x3 = __attribute__((ext_vector_type(3))) unsigned;
+        const u32x3 cw = *(const u32x3*)cp;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const f32x4 b = *(const f32x4*)(sp + (size_t)ch * hw);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = 3 * k + ch;
+                const float a = __fdiv_rn((float)((cw[e >> 2] >> (8 * (e & 3))) & 255u), 255.0f);
+                const float m = (float)mrow[ch * mstep + mx[k]];
+                by[e] = quant1(a * (1.0f - m) + b[k] * m);
+            }
+        }
+        u32x3 wv;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) wv[d] = by[4 * d] | (by[4 * d + 1] << 8) | (by[4 * d + 2] << 16) | (by[4 * d + 3] << 24);
+        *(u32x3*)op = wv;
+    } else {
+        for (int k = 0; k < np; ++k)
+            for (int ch = 0; ch < 3; ++ch) {
+                const float a = __fdiv_rn((float)cp[3 * k + ch], 255.0f), m = (float)mrow[ch * mstep + mx[k]];
+                op[3 * k + ch] = (uint8_t)quant1(a * (1.0f - m) + sp[(size_t)ch * hw + k] * m);
+            }
+    }
+}
+
+int launch_composite_quantize_u8_nearest(const uint8_t* content, const float* stylized, const void* mask, int mask_is_float, int mask_c,
+                                         int mask_n, int mh, int mw, uint8_t* out, int n, int h, int w, hipStream_t s) {
+    if (n < 1 || h < 1 || w < 1 || mh < 1 || mw < 1) { set_error("composite_quantize_u8_nearest: bad shape"); return -1; }
+    if (mask_c != 1 && mask_c != 3) { set_error("composite_quantize_u8_nearest: mask channels %d must be 1 or 3", mask_c); return -1; }
+    if (mask_n != 1 && mask_n != n) { set_error("composite_quantize_u8_nearest: mask batch %d must be 1 or %d", mask_n, n); return -1; }
+    if ((size_t)h * w * 3 >= 0x7fffffffULL || (size_t)mh * mw >= 0x7fffffffULL) { set_error("composite_quantize_u8_nearest: frame or mask too large"); return -1; }
+    dim3 g;
+    if (row_grid("composite_quantize_u8_nearest", n, h, w, &g)) return -1;
+    const int vec = (int)(w % 4 == 0 && aligned16(stylized) && ((uintptr_t)content & 3) == 0 && ((uintptr_t)out & 3) == 0);
+    if (mask_is_float)
+        hipLaunchKernelGGL(composite_quantize_u8_nearest_kernel<float>, g, dim3(64, 4), 0, s, content, stylized, (const float*)mask, mask_c, mask_n, mh, mw, out, h, w, vec);
+    else
+        hipLaunchKernelGGL(composite_quantize_u8_nearest_kernel<uint8_t>, g, dim3(64, 4), 0, s, content, stylized, (const uint8_t*)mask, mask_c, mask_n, mh, mw, out, h, w, vec);
+    return check_launch("composite_quantize_u8_nearest");
+}
+
 // mask.float() of a uint8 / bool mask (test.py:224-226): float(v), element by element
 __global__ __launch_bounds__(256) void mask_to_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

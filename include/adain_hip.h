@@ -166,8 +166,10 @@ ADAIN_API int adain_resize_area_u8(const uint8_t* in_u8, uint8_t* out_u8, int n,
  *                                                                        test.py:222-236  (adain_resize_* + adain_mask_composite)
  *     x*255 + 0.5, clamp, uint8 HWC                adain_quantize_u8      test.py:243-244
  * Every stage runs the kernel of the entry point named beside it with the same arguments, so `out_u8` holds the bytes that
- * sequence of calls gives; when mask, decoder output and frame share one size (the usual case: sides that are multiples of 8,
- * a mask made from the frame itself) the composite's three passes and the quantiser run as one kernel with the same arithmetic.
+ * sequence of calls gives; when decoder output and frame share one size (sides that are multiples of 8) the composite's passes
+ * and the quantiser run as ONE kernel with the same arithmetic - reading the mask in place when it has the frame's size too (a
+ * mask made from the frame itself), sampling it with the nearest resize's index map when it has another (the guide loop: a view
+ * resized to content_size with its mask at the view's own size, Style_3DGS/train.py:97-101).
  * frames HWC uint8 [n][h][w][3]; s_mean / s_std [512]: the style's statistics (adain_encode + adain_mean_std of the style
  * image, once per style); depth_maps / depth_h / depth_w: HOST arrays of n device pointers / sizes; mask [mask_n][mask_c]
  * [mask_h][mask_w], mask_n in {1, n}, mask_c in {1, 3}, uint8 / bool bytes (mask_is_float == 0) or float; out_u8 HWC uint8
