@@ -862,7 +862,7 @@ def main_job(args, ctx):
         if args.layers and layers:
             for i, L in enumerate(layers):
                 print(f"layer {i:2d}: {L['gflop']:8.2f} GF  {L['ms']:8.4f} ms  {L['tflops']:7.2f} TF/s", file=sys.stderr)
-        print(json.dumps(result), flush=True)
+        emit(result)
     ctx.finish()
 
 
@@ -969,12 +969,33 @@ def main_per_call(args, ctx):
     import shutil
 
     shutil.rmtree(root, ignore_errors=True)
-    print(json.dumps(result), flush=True)
+    emit(result)
     ctx.finish()
+
+
+_RESULT_OUT = None
+
+
+def claim_stdout():
+    """stdout carries ONE JSON line.  Native libraries write to file descriptor 1 on their own (RCCL's version banner - NCCL_DEBUG=VERSION
+    is exported on this pool -, gloo's connection notes): from here on descriptor 1 IS stderr, and the result line goes to a private
+    duplicate of the original stdout (``emit``)."""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(result):
+    out = _RESULT_OUT or sys.stdout
+    out.write(json.dumps(result) + "\n")
+    out.flush()
 
 
 def main():
     args = parse_args()
+    claim_stdout()
     ctx = Ctx(args)
     if args.per_call:
         return main_per_call(args, ctx)
@@ -1089,7 +1110,7 @@ def main():
         if args.layers and layers:
             for i, L in enumerate(layers):
                 print(f"layer {i:2d}: {L['gflop']:8.2f} GF  {L['ms']:8.4f} ms  {L['tflops']:7.2f} TF/s", file=sys.stderr)
-        print(json.dumps(result), flush=True)
+        emit(result)
     ctx.finish()
 
 
