@@ -16,6 +16,7 @@ Differences that are deliberate and invisible to callers:
     ``torch.hub`` needs the network; a caller-supplied callable or a precomputed depth map
     (``depth_map=`` keyword of ``adain_inference``) replaces it offline.
 """
+import threading
 import time
 import weakref
 from collections import OrderedDict
@@ -169,6 +170,7 @@ def _as_batch(img, size, crop, device, rgb_only=False):
 # ---------------------------------------------------------------------------------------------------------
 _STYLE_CACHE_SIZE = 16
 _style_cache = OrderedDict()          # key -> (weakref to the style object | None, value)
+_style_cache_lock = threading.Lock()  # the GUI callers run adain_inference on worker threads (one call at a time, but not one thread)
 _style_cache_on = True
 STYLE_ENCODES = [0]                   # style images encoded by adain_inference / get_style_embeddings so far (tests count it)
 
@@ -182,7 +184,8 @@ def set_style_cache(enabled):
 
 
 def clear_style_cache():
-    _style_cache.clear()
+    with _style_cache_lock:
+        _style_cache.clear()
 
 
 def _style_key(style_img, what, style_size, crop, enc, device):
@@ -210,15 +213,17 @@ def _cached_style(style_img, what, style_size, crop, enc, device, make):
     """``make()`` once per style (see ``_style_key``); an LRU of ``_STYLE_CACHE_SIZE`` entries."""
     key, ref = _style_key(style_img, what, style_size, crop, enc, device) if _style_cache_on else (None, None)
     if key is not None:
-        hit = _style_cache.get(key)
-        if hit is not None and (hit[0] is None or hit[0]() is style_img):
-            _style_cache.move_to_end(key)
-            return hit[1]
+        with _style_cache_lock:
+            hit = _style_cache.get(key)
+            if hit is not None and (hit[0] is None or hit[0]() is style_img):
+                _style_cache.move_to_end(key)
+                return hit[1]
     value = make()
     if key is not None:
-        _style_cache[key] = (ref, value)
-        while len(_style_cache) > _STYLE_CACHE_SIZE:
-            _style_cache.popitem(last=False)
+        with _style_cache_lock:
+            _style_cache[key] = (ref, value)
+            while len(_style_cache) > _STYLE_CACHE_SIZE:
+                _style_cache.popitem(last=False)
     return value
 
 

@@ -1076,6 +1076,8 @@ def main():
         result["per_rank"] = per_rank
         if sustained is not None:
             sustained["ratio_to_value"] = round(sustained["value"] / value, 4)
+            sustained["note"] = ("after idling the chip needs about 8 steps (30 ms of load) to reach its sustained clock: with few warm-up steps the K timed "
+                                 "steps still contain the ramp (profiles/r04_step_ramp_after_idle.json, DESIGN.md section 6)")
             result["sustained"] = sustained
         if use_dist:
             result["gather"] = {"mode": args.gather, "in_timed_region": True, "transport": transport, "gathers_in_timed_region": tinfo["gathers"],
