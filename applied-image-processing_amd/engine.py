@@ -206,8 +206,8 @@ def temporal_blend(frames_u8, flows, alpha=0.7):
     out = torch.empty_like(frames_u8)
     if n:
         out[0].copy_(frames_u8[0])
-    for i in range(1, n):
-        out[i].copy_(rt.warp_blend_u8(frames_u8[i], out[i - 1], flows[i - 1], alpha))
+    for i in range(1, n):             # one launch per frame, written straight into the result block (no intermediate, no copy kernel)
+        rt.warp_blend_u8(frames_u8[i], out[i - 1], flows[i - 1], alpha, out=out[i])
     return out
 
 

@@ -471,13 +471,18 @@ def u8_to_f32(frames_u8):
     return out
 
 
-def warp_blend_u8(cur, prev, flow, alpha):
-    """Video post-pass: cur, prev uint8 [h,w,c]; flow float32 [2,h,w] -> blended uint8 [h,w,c]."""
+def warp_blend_u8(cur, prev, flow, alpha, out=None):
+    """Video post-pass: cur, prev uint8 [h,w,c]; flow float32 [2,h,w] -> blended uint8 [h,w,c] (written into ``out`` when given: a
+    contiguous uint8 [h,w,c] GPU tensor that is neither ``cur`` nor ``prev`` - a row of the clip's result block)."""
     cur, prev, flow = _dev(cur, "cur", torch.uint8), _dev(prev, "prev", torch.uint8), _dev(flow, "flow")
     h, w, c = cur.shape
     if prev.shape != cur.shape or tuple(flow.shape) != (2, h, w):
         raise AdainHipError("warp_blend_u8: shape mismatch")
-    out = torch.empty_like(cur)
+    if out is None:
+        out = torch.empty_like(cur)
+    elif (not out.is_cuda or out.dtype != torch.uint8 or out.shape != cur.shape or not out.is_contiguous() or out.device != cur.device
+          or out.data_ptr() in (cur.data_ptr(), prev.data_ptr())):
+        raise AdainHipError(f"warp_blend_u8: out must be a contiguous uint8 {tuple(cur.shape)} tensor on {cur.device}, distinct from cur and prev")
     with torch.cuda.device(cur.device):
         _check(lib().adain_warp_blend_u8(cur.data_ptr(), prev.data_ptr(), flow.data_ptr(), out.data_ptr(), h, w, c, float(alpha),
                                          float(1 - alpha), _stream()), "adain_warp_blend_u8")
