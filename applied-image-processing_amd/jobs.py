@@ -920,8 +920,8 @@ MAX_END_GATHER_BYTES = 64 << 30        # what rank 0 may be asked to hold for on
 
 def run_timed_steps(step, steps, warmup, *, barrier, block_shape, device, mode="end", gather=True, group=None, dst=0,
                     mark=None, elapsed=None):
-    """bench.py's contract around single steps: ``warmup`` untimed steps, ``barrier()``, EXACTLY ``steps`` steps + the path's one
-    collective, ``barrier()``.  Returns ``(seconds as the MAX over the ranks, gathered frames on dst | None, info)``.
+    """bench.py's contract around single steps: (with several ranks: ``barrier()``,) ``warmup`` untimed steps, ``barrier()``, EXACTLY
+    ``steps`` steps + the path's one collective, ``barrier()``.  Returns ``(seconds as the MAX over the ranks, gathered frames on dst | None, info)``.
 
     ``step(out)`` enqueues one pass of the hot path over this rank's ``b`` resident frames and leaves the finished uint8 frames
     in ``out`` [b,H,W,3] (``block_shape`` = (b, H, W, 3)) - or returns another tensor of that shape if it cannot write in place.
@@ -980,12 +980,17 @@ def run_timed_steps(step, steps, warmup, *, barrier, block_shape, device, mode="
             info["gather_bytes"] += n_end * int(np.prod(frame))
             got[0] = sh.gather_frames(keep[:n_end], world * n_end, dst=dst, group=group, counts=[n_end] * world)
 
-    # warm-up: the steps, and - once - the collective in the very shape the timed region issues it (communicator set-up, the
-    # receive buffer's first allocation), all outside the timing
+    # warm-up, all outside the timing: first - once - the end-of-region collective in the very shape the timed region issues it
+    # (communicator set-up, the receive buffer's first allocation), THEN the steps, so that nothing but the barrier lies between
+    # the last warm-up step and the first timed one (the chip loses its clock within milliseconds of idling: DESIGN.md section 6)
+    if gathering and mode == "end":
+        finish()
+    if sh.dist_on():
+        barrier()                         # the ranks start their warm-up steps together, so none idles long at the barrier behind them
     for k in range(warmup):
         one(k)
-    if warmup > 0 or gathering:
-        finish()
+    while pending:                        # mode "overlap": the warm-up steps' own gathers
+        got[0] = pending.pop(0)()
     got[0] = None
     info["gathers"], info["gather_bytes"] = 0, 0
     barrier()

@@ -629,7 +629,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 3 whole jobs with --job)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 1 job with --job)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 5; 1 job with --job)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[] index + 1 (default 2 = configs[1])")
     ap.add_argument("--size", type=int, default=0, help="override content H = W")
     ap.add_argument("--style-size", type=int, default=512, help="style H = W (512 = the API default style_size; SURVEY 8(d) also names the 1024 variant of config 2)")
@@ -665,7 +665,7 @@ def parse_args():
     if args.steps is None:
         args.steps = 3 if args.job else 20
     if args.warmup is None:
-        args.warmup = 1 if args.job else 3
+        args.warmup = 1 if args.job else 5
     if args.batch is None:
         args.batch = 0 if args.job else 1          # --job: 0 = the driver's automatic sub-batch (about three megapixels: 1 frame at 1080p, 2 views at 1200 x 1600)
     return args

@@ -340,7 +340,7 @@ def _steps_worker(rank, world, port, mode, steps, warmup, b, q):
         sh.reset_calls()
         dt, got, info = jobs.run_timed_steps(step, steps, warmup, barrier=lambda: (barriers.append(1), jobs.host_barrier()),
                                              block_shape=(b, 4, 6, 3), device=torch.device("cpu"), mode=mode)
-        assert len(calls) == warmup + steps and len(barriers) == 2 and dt > 0
+        assert len(calls) == warmup + steps and len(barriers) == 3 and dt > 0          # one before the warm-up steps, two around the timed ones
         if mode == "end":                  # ONE gather in the timed region (and one, of the same shape, in the warm-up)
             assert sh.CALLS["gather"] == 2 and info["gathers"] == 1 and info["gather_bytes"] == steps * b * 72
         else:                              # one per step
