@@ -202,3 +202,39 @@ def test_bench_front_door_refuses_more_ranks_than_gpus_before_any_work():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "--gpus 2 means 2 ranks, one per GPU" in r.stderr and "{" not in r.stdout
+
+
+def test_bench_launcher_stops_every_rank_when_one_fails_or_hangs(tmp_path):
+    """``bench.self_launch`` with stand-in rank programs: rank 0 fails after a second while rank 1 would run for a minute -> the
+    launcher reports rank 0's status, stops rank 1 and exits with that status within seconds; ranks that never finish hit the time
+    limit (exit status 124).  The stand-ins also check the environment a rank is started with."""
+    import subprocess
+    import sys
+    import time
+
+    rank_prog = tmp_path / "rank.py"
+    rank_prog.write_text(
+        "import os, sys, time\n"
+        "r = int(os.environ['RANK'])\n"
+        "assert os.environ['WORLD_SIZE'] == '2' and os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "assert os.environ['MASTER_PORT'].isdigit() and os.environ['ADAIN_SELF_LAUNCHED'] == str(os.getppid())\n"
+        "open(os.path.join(os.path.dirname(__file__), f'started_{r}'), 'w').close()\n"
+        "if '--hang' not in sys.argv and r == 0:\n"
+        "    time.sleep(1.0); sys.exit(3)\n"
+        "time.sleep(60)\n")
+    driver = tmp_path / "driver.py"
+    driver.write_text(
+        "import sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        f"bench.__file__ = {str(rank_prog)!r}\n"
+        "bench.self_launch()\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(driver), "--gpus", "2", "--rehearse"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "rank 0 exited with status 3" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert (tmp_path / "started_0").exists() and (tmp_path / "started_1").exists() and time.time() - t0 < 40
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(driver), "--gpus", "2", "--rehearse", "--hang", "--launch-timeout", "3"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 124 and "did not finish within 3 s" in r.stderr and time.time() - t0 < 40, (r.returncode, r.stderr[-500:])
