@@ -238,3 +238,19 @@ def test_bench_launcher_stops_every_rank_when_one_fails_or_hangs(tmp_path):
     r = subprocess.run([sys.executable, str(driver), "--gpus", "2", "--rehearse", "--hang", "--launch-timeout", "3"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode == 124 and "did not finish within 3 s" in r.stderr and time.time() - t0 < 40, (r.returncode, r.stderr[-500:])
+
+
+@pytest.mark.parametrize("header", ["adain_hip.h", "adain_hip_diag.h"])
+def test_headers_are_plain_c_and_cxx(tmp_path, header):
+    """The boundary is a C ABI: both headers compile on their own as strict C99 and as C++17 (no torch, no HIP types in any signature)."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None or shutil.which("g++") is None:
+        pytest.skip("no gcc / g++ here")
+    src = tmp_path / "use.c"
+    src.write_text(f'#include "{header}"\nint main(void) {{ return adain_abi_version() == 0; }}\n')
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c99", "-pedantic-errors", "-Wall", "-Werror", "-fsyntax-only"], ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++"]):
+        r = subprocess.run(cmd + ["-I", inc, str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
