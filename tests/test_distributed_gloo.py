@@ -472,3 +472,45 @@ def test_automatic_sub_batch_follows_the_frame_size():
     fixed, _ = jobs.stylize_frames_sharded(StubEngine(), frames, style, masks=masks, sub_batch=2, gather=False)
     assert [tuple(b.shape) for b in auto] == [(4, 12, 20, 3), (1, 8, 20, 3), (4, 12, 20, 3)] and info["feeder"]["batches"] == 3
     assert torch.equal(torch.cat([b.reshape(-1) for b in auto]), torch.cat([b.reshape(-1) for b in fixed]))
+
+
+def test_file_sink_bounds_the_blocks_in_flight(tmp_path):
+    """FileSink.write blocks once ``max_in_flight`` blocks wait for their writers (advisor finding: a slow encoder must not pin the
+    whole job in host memory); every file is written, errors surface in close()."""
+    import threading
+
+    from PIL import Image
+
+    gate = threading.Event()
+    sink = jobs.FileSink(torch.device("cpu"), workers=1, max_in_flight=2)
+    real_save = sink._save
+    in_save = []
+
+    def slow_save(arr, path):
+        in_save.append(path)
+        gate.wait(10)
+        real_save(arr, path)
+
+    sink._save = slow_save
+    blocks = [torch.full((1, 6, 8, 3), k, dtype=torch.uint8) for k in range(4)]
+    done = []
+
+    def producer():
+        for k, b in enumerate(blocks):
+            sink.write(b, [tmp_path / f"f{k}.png"])
+            done.append(k)
+
+    t = threading.Thread(target=producer)
+    t.start()
+    time.sleep(0.5)
+    assert done == [0, 1] and len(in_save) == 1                 # two blocks accepted, the third write is waiting for a free slot
+    gate.set()
+    t.join(20)
+    sink.close()
+    assert done == [0, 1, 2, 3] and sink.wait_s > 0.3
+    for k in range(4):
+        assert np.asarray(Image.open(tmp_path / f"f{k}.png"))[0, 0, 0] == k
+    bad = jobs.FileSink(torch.device("cpu"), workers=1)
+    bad.write(blocks[0], [tmp_path / "no_such_dir" / "x.png"])
+    with pytest.raises(OSError):
+        bad.close()
