@@ -201,6 +201,104 @@ size_t adain_encode_multi_workspace_bytes(int count, const int* n, const int* h,
     return total;
 }
 
+// ---- batches of LARGE frames: which layers run frame by frame ------------------------------------------------------------------
+// Measured per layer (profiles/r04_batching_per_layer.md): with >= 2 Mpixel frames a launch over the whole batch costs the
+// mid-network layers 4-6 % against one launch per frame in frame-major order (a batch's activations no longer sit in the 256 MB
+// Infinity Cache when their consumer comes), while the small relu4-level layers GAIN from the batch (one 1080p frame is 2.1 rounds
+// of work for the resident workgroups in dec1, run in 3).  So a batch runs its BIG layers frame by frame - everything from the
+// image down to the last big layer for frame 0, then for frame 1, ... - and the layers behind them once over all frames.  "Big" =
+// one frame alone is worth at least BIG_LAYER_ROUNDS rounds of the persistent grid; frames below about a megapixel have no big
+// layer and run as before (every layer over the batch, which is what fills the chip there).  Results do not depend on the split.
+constexpr double BIG_LAYER_ROUNDS = 6.0;
+
+// encoder: number of leading generic layers (0..8) run frame by frame = index after the LAST big layer
+static int enc_frame_major_layers(int n, int h, int w) {
+    if (n < 2) return 0;
+    int k = 0, ch = h, cw = w;
+    for (int l = 0; l < 8; ++l) {
+        if (wino4_rounds_per_image(ch, cw, ENC[l].cout) >= BIG_LAYER_ROUNDS) k = l + 1;
+        if (ENC[l].pool) { ch = (ch + 1) / 2; cw = (cw + 1) / 2; }
+    }
+    return k;
+}
+// decoder: number of leading layers (0..8) run over the whole batch = index of the FIRST big layer (8: none is big)
+static int dec_batched_layers(int n, int hc, int wc) {
+    if (n < 2) return 8;
+    int ch = hc, cw = wc;
+    for (int l = 0; l < 8; ++l) {
+        if (DEC[l].src == SRC_UP2X) { ch *= 2; cw *= 2; }
+        if (wino4_rounds_per_image(ch, cw, DEC[l].cout) >= BIG_LAYER_ROUNDS) return l;
+    }
+    return 8;
+}
+
+// The frame-major pass shares the layer-major schedule's two ping-pong buffers (image i's tensor of a layer sits at i x that layer's
+// per-image size, where the batched layers behind expect it), so an image processed later must never write over the LAST
+// frame-major tensor of an image processed earlier.  With VGG's sizes it never does (later tensors of the same buffer are
+// larger and start further out); this replays the offsets and says so for the case at hand - if not, the schedule stays layer-major.
+static bool enc_frame_major_is_safe(int n, int h, int w, int k) {
+    if (k < 1) return false;
+    size_t size[8];                    // per-image floats of layer l's output
+    int ch = h, cw = w;
+    for (int l = 0; l < k; ++l) {
+        if (ENC[l].pool) { ch = (ch + 1) / 2; cw = (cw + 1) / 2; }
+        size[l] = (size_t)ch * cw * ENC[l].cout;
+    }
+    const int last_buf = (k - 1) & 1 ? 0 : 1;          // layer l writes buffer B (1) for even l, A (0) for odd l
+    const size_t keep = size[k - 1];
+    for (int j = 1; j < n; ++j) {                      // image j's writes against the kept tensors of images 0 .. j-1: [0, j * keep)
+        if (last_buf == 0 && (size_t)j * h * w * 64 < (size_t)j * keep) return false;                 // conv_first -> buffer A
+        for (int l = 0; l + 1 < k; ++l)
+            if (((l & 1) ? 0 : 1) == last_buf && (size_t)j * size[l] < (size_t)j * keep) return false;
+    }
+    return true;
+}
+// decoder, images processed LAST to FIRST: image j's writes into the buffer that holds the batched layers' output must stay behind
+// the tensors of the images still waiting, [0, j x that tensor's size)
+static bool dec_frame_major_is_safe(int n, int hc, int wc, int batched) {
+    if (batched < 1 || batched > 7) return true;       // 0: the input is the caller's feature tensor; 8: nothing runs frame by frame
+    size_t size[8];
+    int ch = hc, cw = wc;
+    for (int l = 0; l < 8; ++l) {
+        if (DEC[l].src == SRC_UP2X) { ch *= 2; cw *= 2; }
+        size[l] = (size_t)ch * cw * DEC[l].cout;
+    }
+    const int in_buf = (batched - 1) & 1;               // layer l writes buffer B (1) for odd l, A (0) for even l
+    for (int l = batched; l < 8; ++l)
+        if ((l & 1) == in_buf && size[l] < size[batched - 1]) return false;
+    (void)n;
+    return true;
+}
+
+// one batch of n images [n][h][w]: the frame-major part of the encoder (conv_first + the first k generic layers, image by image),
+// leaving layer k - 1's output for all images contiguous in *cur_out (dims *ch_out x *cw_out) exactly where the layer-major
+// schedule would have put it
+static int encode_frame_major(const void* images, int u8, int n, int h, int w, int k, const float* packed, const Offsets& f, float* bufA,
+                              float* bufB, const float** cur_out, int* ch_out, int* cw_out, hipStream_t s) {
+    const size_t img_stride = (size_t)h * w * 3 * (u8 ? 1 : 4);      // bytes per source image
+    int ch = h, cw = w;
+    const float* cur = bufA;
+    for (int i = 0; i < n; ++i) {
+        RET_IF(launch_conv_first((const char*)images + (size_t)i * img_stride, u8, bufA + (size_t)i * h * w * 64, packed, packed + f.first_b, 1, h, w, s));
+        cur = bufA;
+        ch = h; cw = w;
+        for (int l = 0; l < k; ++l) {
+            float* out = cur == bufA ? bufB : bufA;
+            const int oh = ENC[l].pool ? (ch + 1) / 2 : ch, ow = ENC[l].pool ? (cw + 1) / 2 : cw;
+            ConvArgs a{};
+            a.cin = ENC[l].cin; a.cout = ENC[l].cout; a.relu = 1; a.pool_out = ENC[l].pool;
+            a.bias = packed + f.b[l]; a.wpk = packed + f.w[l];
+            a.in = cur + (size_t)i * ch * cw * ENC[l].cin;
+            a.out = out + (size_t)i * oh * ow * ENC[l].cout;
+            a.n = 1; a.H = a.Hs = ch; a.W = a.Ws = cw;
+            RET_IF(launch_conv3x3_wino4(a, ENC[l].src, s));
+            cur = out; ch = oh; cw = ow;
+        }
+    }
+    *cur_out = cur; *ch_out = ch; *cw_out = cw;
+    return 0;
+}
+
 // images[i]: NCHW float, or (u8 != 0) HWC uint8 converted as ToTensor does inside the first layer's kernel
 static int encode_impl(int count, const void* const* images, int u8, float* const* feats, const int* n, const int* h, const int* w,
                        const float* packed, void* workspace, size_t ws_bytes, void* const* ev, adain_stream_t stream) {
@@ -223,17 +321,24 @@ static int encode_impl(int count, const void* const* images, int u8, float* cons
     int ch[MAX_CONV_SEGS], cw[MAX_CONV_SEGS];
     float* base = (float*)workspace;
     record(ev, 0, s);
+    const bool wino4 = conv_form() == FORM_WINO4;
+    // a batch of large frames (one tensor pair, no per-layer events wanted): its big layers frame by frame, see above
+    int frame_major = (count == 1 && wino4 && !ev) ? enc_frame_major_layers(n[0], h[0], w[0]) : 0;
+    if (frame_major && !enc_frame_major_is_safe(n[0], h[0], w[0], frame_major)) frame_major = 0;
     for (int i = 0; i < count; ++i) {
         bufA[i] = base;
         bufB[i] = base + enc_buf_a(n[i], h[i], w[i]);
         base = bufB[i] + enc_buf_b(n[i], h[i], w[i]);
+        if (frame_major) {
+            RET_IF(encode_frame_major(images[i], u8, n[i], h[i], w[i], frame_major, packed, f, bufA[i], bufB[i], &cur[i], &ch[i], &cw[i], s));
+            continue;
+        }
         RET_IF(launch_conv_first(images[i], u8, bufA[i], packed, packed + f.first_b, n[i], h[i], w[i], s));
         cur[i] = bufA[i];
         ch[i] = h[i]; cw[i] = w[i];
     }
     record(ev, 1, s);
-    const bool wino4 = conv_form() == FORM_WINO4;
-    for (int l = 0; l < 8; ++l) {
+    for (int l = frame_major; l < 8; ++l) {
         ConvArgs a{};
         a.cin = ENC[l].cin; a.cout = ENC[l].cout;
         a.relu = 1;
@@ -301,7 +406,11 @@ int adain_decode(const float* feat, float* image, const float* packed, void* wor
     const float* cur = feat;
     int ch = hc, cw = wc;
     record(ev, 0, s);
-    for (int i = 0; i < 8; ++i) {
+    // a batch of large frames: the leading small layers over the whole batch, then everything from the first big layer to the
+    // image frame by frame (see enc_frame_major_layers)
+    int batched = (conv_form() == FORM_WINO4 && !ev) ? dec_batched_layers(n, hc, wc) : 8;
+    if (!dec_frame_major_is_safe(n, hc, wc, batched)) batched = 8;
+    for (int i = 0; i < batched; ++i) {
         ConvArgs a{};
         a.in = cur;
         a.out = (i & 1) ? bufB : bufA;
@@ -315,8 +424,31 @@ int adain_decode(const float* feat, float* image, const float* packed, void* wor
         record(ev, i + 1, s);
         cur = a.out;
     }
-    RET_IF(launch_conv_last(cur, image, packed + f.last_w, packed + f.last_b, n, ch, cw, s));
-    record(ev, 9, s);
+    if (batched == 8) {
+        RET_IF(launch_conv_last(cur, image, packed + f.last_w, packed + f.last_b, n, ch, cw, s));
+        record(ev, 9, s);
+        return 0;
+    }
+    const int ch0 = ch, cw0 = cw;                                   // size of layer `batched`'s source, per image
+    for (int img = n - 1; img >= 0; --img) {                        // last to first: see dec_frame_major_is_safe
+        const float* c = cur;
+        ch = ch0; cw = cw0;
+        for (int i = batched; i < 8; ++i) {
+            ConvArgs a{};
+            a.cin = DEC[i].cin; a.cout = DEC[i].cout; a.relu = 1;
+            a.bias = packed + f.b[i]; a.wpk = packed + f.w[i];
+            a.in = c + (size_t)img * ch * cw * DEC[i].cin;
+            a.n = 1;
+            a.Hs = ch; a.Ws = cw;
+            if (DEC[i].src == SRC_UP2X) { ch *= 2; cw *= 2; }
+            a.H = ch; a.W = cw;
+            float* out = (i & 1) ? bufB : bufA;
+            a.out = out + (size_t)img * ch * cw * DEC[i].cout;
+            RET_IF(launch_conv3x3_wino4(a, DEC[i].src, s));
+            c = out;
+        }
+        RET_IF(launch_conv_last(c + (size_t)img * ch * cw * 64, image + (size_t)img * 3 * ch * cw, packed + f.last_w, packed + f.last_b, 1, ch, cw, s));
+    }
     return 0;
 }
 

@@ -92,6 +92,7 @@ int launch_conv3x3_wino4(const ConvArgs& a, int src_mode, hipStream_t s);
 // the same layer over `count` tensor pairs (sizes / addresses from segs[i]: in, out, n, H, W, Hs, Ws; the rest from `layer`):
 // one persistent launch whose tile list covers every segment when there is enough work, one launch per segment otherwise
 int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int count, int src_mode, hipStream_t s);
+double wino4_rounds_per_image(int H, int W, int cout);      // persistent-grid rounds one image of a layer is worth (schedules, api.hip)
 // conv_wino3.hip
 int launch_conv3x3_wino3(const ConvArgs& a, int src_mode, hipStream_t s);
 // img: NCHW float [n][3][H][W], or (u8 != 0) HWC uint8 [n][H][W][3] converted as ToTensor does (v / 255)

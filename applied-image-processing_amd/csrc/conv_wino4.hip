@@ -809,6 +809,18 @@ static int pick_geo(const ConvSeg* segs, int count) {
     return t1 * 101 < t0 * 100 ? 1 : 0;
 }
 
+// Rounds of the persistent grid that ONE image of a layer is worth: tiles of the geometry its launch would pick x channel tiles over
+// the resident workgroups.  The encoder / decoder schedules (api.hip) use it to decide which layers of a batch of large frames run
+// frame by frame and which over the whole batch.
+double wino4_rounds_per_image(int H, int W, int cout) {
+    const long long pgrid = persistent_grid();
+    if (pgrid <= 0 || H < 1 || W < 1) return 0.0;
+    ConvSeg s{};
+    s.n = 1; s.H = H; s.W = W;
+    const int geo = pick_geo(&s, 1);
+    return (double)geo_tiles(geo, 1, H, W) * (cout / 32) / (double)pgrid;
+}
+
 template <int MODE, bool PERSIST, bool BIG>
 static void w4_launch_geo(int geo, dim3 grid, hipStream_t s, const ConvArgs& a, const ConvSegs& m, int items, int prio) {
     if constexpr (!BIG) {       // (per-tile descriptors - tensors of 2 GiB and more - exist for the default geometry only: see pick_geo's callers)

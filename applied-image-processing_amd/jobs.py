@@ -93,10 +93,18 @@ def as_frame(x):
 # for 512 resident workgroups); large ones lose to the L2-miss traffic that grows faster than the batch.
 AUTO_SUB_BATCH_PIXELS = 3.0e6
 MAX_AUTO_SUB_BATCH = 32
+# Frames of 1.5 - 3 megapixels (1080p, 1200 x 1600): since round 4 the C schedules run a batch's big layers frame by frame and only its
+# relu4-level layers over the whole batch (csrc/api.hip, BIG_LAYER_ROUNDS), so a sub-batch no longer costs the mid-network layers
+# anything and fills the last round of conv4_1 / dec1: per step 331.1 / 331.8 / 334.9 Mpixels/s at 1 / 2 / 4 frames of 1080p, 324.1 /
+# 326.1 / 328.2 at 1200 x 1600 (same box).  Larger frames have no layer left that a batch would help.
+LARGE_FRAME_PIXELS = (1.5e6, 3.0e6)
+LARGE_FRAME_SUB_BATCH = 4
 MAX_QUEUED_BATCHES = 6             # sub-batches enqueued ahead of the device (stylize_frames_sharded)
 
 
 def auto_sub_batch(h, w):
+    if LARGE_FRAME_PIXELS[0] <= h * w < LARGE_FRAME_PIXELS[1]:
+        return LARGE_FRAME_SUB_BATCH
     return int(max(1, min(MAX_AUTO_SUB_BATCH, round(AUTO_SUB_BATCH_PIXELS / max(1, h * w)))))
 
 
@@ -520,7 +528,7 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
                     ``depth_offset`` / ``depth_prominence``; otherwise the ``alpha`` blend (test.py:74-81).
     masks           optional sequence of [1|3,hm,wm] masks -> content-mask composite (test.py:222-236).
     sub_batch       frames per sub-batch; None (default) = chosen from the frame size, about three megapixels per sub-batch
-                    (``auto_sub_batch``: 26 frames of 256 x 456, 6 of 512 x 912, 2 of 1200 x 1600, 1 of 1080p - inside the measured optima).
+                    (``auto_sub_batch``: 26 frames of 256 x 456, 6 of 512 x 912; 4 of 1080p or 1200 x 1600 - inside the measured optima).
     post            optional ``f(u8_block) -> u8_block`` applied per sub-batch on the owning rank BEFORE the gather
                     (frame-local work such as the INTER_AREA resize, so the gather moves the small frames).
     sink            optional ``f(i, j, u8_block)`` called with every finished sub-batch (frames i..j-1) on the owning rank.

@@ -634,7 +634,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=0, help="override content H = W")
     ap.add_argument("--style-size", type=int, default=512, help="style H = W (512 = the API default style_size; SURVEY 8(d) also names the 1024 variant of config 2)")
     ap.add_argument("--alpha", type=float, default=0.5, help="configs 2 / 4 / 5: content-style trade-off of the alpha blend (default 0.5; SURVEY 8(d) also names 1.0)")
-    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 1); with --job: frames per sub-batch (default: chosen by the driver from the frame size, jobs.auto_sub_batch: 1 at 1080p; sub-batches of 1 / 2 / 4 / 8 / 16 measured 319 / 317 / 313 / 307 / 303 Mpixels/s there, while 256 x 456 frames peak at 16)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 1); with --job: frames per sub-batch (default: chosen by the driver from the frame size, jobs.auto_sub_batch: 4 at 1080p and 1200 x 1600 - the C schedules run a batch's big layers frame by frame -, about three megapixels for smaller frames: 256 x 456 frames peak at 16 - 32)")
     ap.add_argument("--depth", action="store_true", help="config 4: the depth-aware variant (a synthetic proximity map per frame, use_depth=True of the reference's video caller: offset 0.30, prominence 20)")
     ap.add_argument("--job", action="store_true", help="configs 4 / 5: run the BASELINE job (512 frames / 300 views) strong-scaled over the ranks")
     ap.add_argument("--frames", type=int, default=0, help="--job: frames of the whole job (default 512 / 300)")
@@ -667,7 +667,7 @@ def parse_args():
     if args.warmup is None:
         args.warmup = 1 if args.job else 5
     if args.batch is None:
-        args.batch = 0 if args.job else 1          # --job: 0 = the driver's automatic sub-batch (about three megapixels: 1 frame at 1080p, 2 views at 1200 x 1600)
+        args.batch = 0 if args.job else 1          # --job: 0 = the driver's automatic sub-batch (4 frames of 1080p / 1200 x 1600, about three megapixels of smaller frames)
     return args
 
 

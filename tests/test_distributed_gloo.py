@@ -462,9 +462,9 @@ def test_masks_of_mixed_sizes_inside_one_sub_batch():
 
 
 def test_automatic_sub_batch_follows_the_frame_size():
-    """sub_batch=None: about three megapixels per sub-batch (26 frames of 256 x 456, 6 of 512 x 912, 2 of 1200 x 1600, 1 of 1080p),
-    per run of equal-sized frames; results do not depend on the cut."""
-    assert [jobs.auto_sub_batch(*hw) for hw in ((256, 456), (512, 912), (1080, 1920), (1200, 1600), (64, 64), (4096, 2208))] == [26, 6, 1, 2, 32, 1]
+    """sub_batch=None: about three megapixels per sub-batch (26 frames of 256 x 456, 6 of 512 x 912), 4 frames of 1.5 - 3 megapixels
+    (1080p, 1200 x 1600), 1 beyond, per run of equal-sized frames; results do not depend on the cut."""
+    assert [jobs.auto_sub_batch(*hw) for hw in ((256, 456), (512, 912), (1080, 1920), (1200, 1600), (64, 64), (4096, 2208), (1440, 2560))] == [26, 6, 4, 4, 32, 1, 1]
     frames, masks = _u8_inputs(9)
     frames[4], masks[4] = frames[4][:8], masks[4][:, :8]                     # one frame of another size in the middle
     style = torch.full((1, 3, 4, 4), 0.3)
