@@ -834,11 +834,14 @@ def main_job(args, ctx):
         parallelism = (f"frame sharding x{world}: contiguous blocks {shard if world > 1 else ''} per rank, replicated weights and style statistics, "
                        f"one status word + ONE gather of the uint8 frames to rank 0 per job" if ctx.use_dist else "single GPU, no collective")
         result = base_result(args, ctx, value, sec_per_job * 1e3, workload, parallelism, "strong")
-        step = Step(device, config=cfg, first_frame=0, style_size=args.style_size, batch=sub, engine=engine, weights=weights, depth=args.depth, alpha=args.alpha)
+        # the roofline of a job line is taken on ONE frame: the C schedules run a sub-batch's big layers frame by frame (and the
+        # per-layer events of the instrumented run would switch that schedule off for a batch)
+        step = Step(device, config=cfg, first_frame=0, style_size=args.style_size, batch=1, engine=engine, weights=weights, depth=args.depth, alpha=args.alpha)
         roof, layers, secondary = measure_roofline(step, 5)
+        roof["measured_on"] = "one frame of the job (batch 1), HIP events per conv launch"
         result["roofline"] = roof
         result["secondary"] = secondary
-        result["step_tflops"] = round((step.flops_per_step() / sub * n_total) / sec_per_job / 1e12, 2)
+        result["step_tflops"] = round((step.flops_per_step() * n_total) / sec_per_job / 1e12, 2)
         result["job"] = {"driver": "jobs.stylize_frames_sharded", "frames": n_total, "frames_per_rank": shard, "sub_batch": sub,
                          "gathers_per_job": info["gathers"], "gather_chunks": args.gather_chunks, "transport": ctx.transport,
                          "per_rank": per_rank, "ms_per_frame": round(sec_per_job * 1e3 / max(shard), 4)}
