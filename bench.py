@@ -502,6 +502,9 @@ def measure_roofline(step, reps):
         "algorithmic_tflops": round(algorithmic, 2),
         "algorithmic_bytes_per_launch_avg": sum(step.conv3x3_algorithmic_bytes()) / len(flops),
     }
+    if step.batch > 1:
+        roof["note"] = ("batch > 1: the instrumented passes (per-layer events) run every layer once over the whole batch; the timed steps run a "
+                        "batch's big layers frame by frame (csrc/api.hip, BIG_LAYER_ROUNDS), which is faster for >= 2 Mpixel frames")
     secondary = []
     for name, (nbytes, ms, cnt) in sec.items():
         us = ms / cnt * 1e3
