@@ -201,33 +201,45 @@ size_t adain_encode_multi_workspace_bytes(int count, const int* n, const int* h,
     return total;
 }
 
-// ---- batches of LARGE frames: which layers run frame by frame ------------------------------------------------------------------
-// Measured per layer (profiles/r04_batching_per_layer.md): with >= 2 Mpixel frames a launch over the whole batch costs the
-// mid-network layers 4-6 % against one launch per frame in frame-major order (a batch's activations no longer sit in the 256 MB
-// Infinity Cache when their consumer comes), while the small relu4-level layers GAIN from the batch (one 1080p frame is 2.1 rounds
-// of work for the resident workgroups in dec1, run in 3).  So a batch runs its BIG layers frame by frame - everything from the
-// image down to the last big layer for frame 0, then for frame 1, ... - and the layers behind them once over all frames.  "Big" =
-// one frame alone is worth at least BIG_LAYER_ROUNDS rounds of the persistent grid; frames below about a megapixel have no big
-// layer and run as before (every layer over the batch, which is what fills the chip there).  Results do not depend on the split.
+// ---- batches of WIDE frames: which layers run frame by frame -----------------------------------------------------------------------
+// Measured (profiles/r04_batching_per_layer.md, tools/probes/frame_major_ab.sh): for 1080p and 1200 x 1600 frames a launch over a
+// whole batch costs the mid-network layers a few per cent against one launch per frame in frame-major order, while the small
+// relu4-level layers GAIN from the batch (one 1080p frame is 2.1 rounds of work for the resident workgroups in dec1, run in 3).
+// Same-box A/B of the two schedules at batch 2 / 4: W = 1920 +0.5 / +1.7 %, W = 1600 +0.4 / +1.3 %, W = 1536 +0.3 %, but W = 1408
+// -1.2 / -0.4 %, W = 1280 -1.0 / -1.6 %, W = 960 -1.8 %: the sign follows the frame's WIDTH - a tile row of the 128-channel half-size
+// layers (10 halo rows x W/2 pixels x 512 B) outgrows an XCD's 4 MB L2 at W = 1638 - and below it a batch only helps (fewer launch
+// ramps, fuller last rounds).  So a batch of frames at least BIG_FRAME_WIDTH wide runs its BIG layers - one frame alone is worth at
+// least BIG_LAYER_ROUNDS rounds of the persistent grid - frame by frame (everything from the image down to the last big layer for
+// frame 0, then for frame 1, ...) and only the layers behind them once over all frames; narrower frames run every layer over the
+// batch, as they always did.  Results do not depend on the split.
 constexpr double BIG_LAYER_ROUNDS = 6.0;
+constexpr int BIG_FRAME_WIDTH = 1600;
+static double big_layer_rounds() {           // (diagnostic build: ADAIN_BIG_ROUNDS_X10, e.g. 10000000 = never frame by frame)
+    static const int v = tune_env("ADAIN_BIG_ROUNDS_X10", (int)(BIG_LAYER_ROUNDS * 10));
+    return v / 10.0;
+}
+static int big_frame_width() {               // (diagnostic build: ADAIN_BIG_FRAME_WIDTH, 0 = any width)
+    static const int v = tune_env("ADAIN_BIG_FRAME_WIDTH", BIG_FRAME_WIDTH);
+    return v;
+}
 
 // encoder: number of leading generic layers (0..8) run frame by frame = index after the LAST big layer
 static int enc_frame_major_layers(int n, int h, int w) {
-    if (n < 2) return 0;
+    if (n < 2 || w < big_frame_width()) return 0;
     int k = 0, ch = h, cw = w;
     for (int l = 0; l < 8; ++l) {
-        if (wino4_rounds_per_image(ch, cw, ENC[l].cout) >= BIG_LAYER_ROUNDS) k = l + 1;
+        if (wino4_rounds_per_image(ch, cw, ENC[l].cout) >= big_layer_rounds()) k = l + 1;
         if (ENC[l].pool) { ch = (ch + 1) / 2; cw = (cw + 1) / 2; }
     }
     return k;
 }
 // decoder: number of leading layers (0..8) run over the whole batch = index of the FIRST big layer (8: none is big)
 static int dec_batched_layers(int n, int hc, int wc) {
-    if (n < 2) return 8;
+    if (n < 2 || 8 * wc < big_frame_width()) return 8;
     int ch = hc, cw = wc;
     for (int l = 0; l < 8; ++l) {
         if (DEC[l].src == SRC_UP2X) { ch *= 2; cw *= 2; }
-        if (wino4_rounds_per_image(ch, cw, DEC[l].cout) >= BIG_LAYER_ROUNDS) return l;
+        if (wino4_rounds_per_image(ch, cw, DEC[l].cout) >= big_layer_rounds()) return l;
     }
     return 8;
 }

@@ -93,10 +93,11 @@ def as_frame(x):
 # for 512 resident workgroups); large ones lose to the L2-miss traffic that grows faster than the batch.
 AUTO_SUB_BATCH_PIXELS = 3.0e6
 MAX_AUTO_SUB_BATCH = 32
-# Frames of 1.5 - 3 megapixels (1080p, 1200 x 1600): since round 4 the C schedules run a batch's big layers frame by frame and only its
-# relu4-level layers over the whole batch (csrc/api.hip, BIG_LAYER_ROUNDS), so a sub-batch no longer costs the mid-network layers
-# anything and fills the last round of conv4_1 / dec1: per step 331.1 / 331.8 / 334.9 Mpixels/s at 1 / 2 / 4 frames of 1080p, 324.1 /
-# 326.1 / 328.2 at 1200 x 1600 (same box).  Larger frames have no layer left that a batch would help.
+# Frames of 1.5 - 3 megapixels (1080p, 1200 x 1600, 1408 x 1408): since round 4 the C schedules run the big layers of a batch of WIDE
+# frames frame by frame and only its relu4-level layers over the whole batch (csrc/api.hip, BIG_FRAME_WIDTH / BIG_LAYER_ROUNDS), so a
+# sub-batch no longer costs the mid-network layers anything and fills the last round of conv4_1 / dec1: per step 331.1 / 331.8 / 334.9
+# Mpixels/s at 1 / 2 / 4 frames of 1080p, 324.1 / 326.1 / 328.2 at 1200 x 1600 (same box); narrower frames of that size always gained
+# from a batch (1280 x 1280: 335.5 / 337.5 at 2 / 4).  Larger frames have no layer left that a batch would help.
 LARGE_FRAME_PIXELS = (1.5e6, 3.0e6)
 LARGE_FRAME_SUB_BATCH = 4
 MAX_QUEUED_BATCHES = 6             # sub-batches enqueued ahead of the device (stylize_frames_sharded)

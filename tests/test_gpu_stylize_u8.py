@@ -140,11 +140,12 @@ def test_random_shapes_depth_and_mask_together(engine):
         assert got.shape == (n, h, w, 3) and torch.equal(got, want), (case, n, h, w, mn, mc, mh, mw, str(m.dtype))
 
 
-@pytest.mark.parametrize("n,h,w", [(3, 1080, 1920), (2, 1200, 1600), (4, 520, 776), (2, 768, 1024)])
+@pytest.mark.parametrize("n,h,w", [(3, 1080, 1920), (2, 1200, 1600), (2, 264, 1720), (4, 520, 776), (2, 1408, 1408)])
 def test_batches_of_large_frames_two_phase_schedule_equals_frame_by_frame(rt, engine, n, h, w):
-    """Batches of LARGE frames run their big layers frame by frame and only the relu4-level layers over the whole batch (csrc/api.hip,
-    BIG_LAYER_ROUNDS; 1080p: everything but conv4_1 / dec1; 520 x 776: conv1_2 / dec8 only): the result must be, bit for bit, what
-    each frame gives on its own - through the one-call entry point and through encode / decode on float frames."""
+    """Batches of WIDE frames (>= 1600 pixels) run their big layers frame by frame and only the layers behind them over the whole batch
+    (csrc/api.hip, BIG_FRAME_WIDTH / BIG_LAYER_ROUNDS; 1080p: everything but conv4_1 / dec1; a 264 x 1720 strip: the outer layers only),
+    narrower ones every layer over the batch: either way the result must be, bit for bit, what each frame gives on its own - through
+    the one-call entry point and through encode / decode on float frames."""
     x = u8frames(1100 + h, n, h, w).cuda()
     m = (x > 40).permute(0, 3, 1, 2).contiguous()
     got = engine.stylize_u8(x, alpha=0.5, masks=m)
