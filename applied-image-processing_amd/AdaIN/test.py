@@ -188,9 +188,27 @@ def clear_style_cache():
         _style_cache.clear()
 
 
+def _pixel_fingerprint(img):
+    """A fingerprint of a PIL image's pixels that moves when the image is edited IN PLACE (paste / draw / a GUI reusing one buffer):
+    the per-row and per-64-word-column wrap-around sums of ``img.tobytes()`` read as uint64 words - position-sensitive in both
+    directions; the cost is the ``tobytes`` copy (about 1 ms for a 933 x 700 image) plus two streaming passes (0.2 ms).  (Pillow's
+    zero-copy Arrow export would avoid the copy; it crashed on small images with Pillow 12.2 here, so it is not used.)
+    None = cannot fingerprint (the style is then not cached)."""
+    try:
+        a = np.frombuffer(img.tobytes(), np.uint8)
+        n8 = a.size // 8 * 8
+        w = a[:n8].view(np.uint64)
+        r = w.size // 64
+        body = w[: r * 64].reshape(r, 64)
+        return hash((body.sum(axis=0).tobytes(), body.sum(axis=1).tobytes(), w[r * 64:].tobytes(), a[n8:].tobytes()))
+    except Exception:
+        return None
+
+
 def _style_key(style_img, what, style_size, crop, enc, device):
     """Cache key of a style image: a file by (resolved path, mtime, size) - a rewritten file is another style -, an image object
-    by identity (guarded by a weak reference: a dead object's id may be reused), plus everything else the result depends on:
+    by identity (guarded by a weak reference: a dead object's id may be reused) AND a fingerprint of its pixels (an object edited
+    in place is another style: the reference re-encodes every call, test.py:63 / :77), plus everything else the result depends on:
     ``style_size``, ``crop``, the device and the encoder's parameter state (``load_state_dict`` / ``.to()`` / in-place edits
     all change it).  None = not cacheable."""
     params = (str(device),) + _param_state(enc)
@@ -205,7 +223,10 @@ def _style_key(style_img, what, style_size, crop, enc, device):
         ref = weakref.ref(style_img)
     except TypeError:
         return None, None
-    return (what, "object", id(style_img), getattr(style_img, "size", None), getattr(style_img, "mode", None), int(style_size), bool(crop),
+    fp = _pixel_fingerprint(style_img)
+    if fp is None:
+        return None, None
+    return (what, "object", id(style_img), fp, getattr(style_img, "size", None), getattr(style_img, "mode", None), int(style_size), bool(crop),
             params), ref
 
 

@@ -223,11 +223,13 @@ static int big_frame_width() {               // (diagnostic build: ADAIN_BIG_FRA
     return v;
 }
 
-// encoder: number of leading generic layers (0..8) run frame by frame = index after the LAST big layer
+// encoder: number of leading generic layers (0..7) run frame by frame = index after the LAST big layer.  conv4_1 (layer 7) is never
+// part of the prefix: it writes the caller's feature tensors, not the ping-pong buffers the frame-major pass works in, so it always
+// runs over the whole batch in the layer-major loop behind (a 1440 x 2560 frame's conv4_1 is 7.2 rounds and would count as big).
 static int enc_frame_major_layers(int n, int h, int w) {
     if (n < 2 || w < big_frame_width()) return 0;
     int k = 0, ch = h, cw = w;
-    for (int l = 0; l < 8; ++l) {
+    for (int l = 0; l < 7; ++l) {
         if (wino4_rounds_per_image(ch, cw, ENC[l].cout) >= big_layer_rounds()) k = l + 1;
         if (ENC[l].pool) { ch = (ch + 1) / 2; cw = (cw + 1) / 2; }
     }
@@ -258,11 +260,12 @@ static bool enc_frame_major_is_safe(int n, int h, int w, int k) {
     }
     const int last_buf = (k - 1) & 1 ? 0 : 1;          // layer l writes buffer B (1) for even l, A (0) for odd l
     const size_t keep = size[k - 1];
-    for (int j = 1; j < n; ++j) {                      // image j's writes against the kept tensors of images 0 .. j-1: [0, j * keep)
-        if (last_buf == 0 && (size_t)j * h * w * 64 < (size_t)j * keep) return false;                 // conv_first -> buffer A
-        for (int l = 0; l + 1 < k; ++l)
-            if (((l & 1) ? 0 : 1) == last_buf && (size_t)j * size[l] < (size_t)j * keep) return false;
-    }
+    // image j writes layer l's tensor at j * size[l]; the kept tensors of images 0 .. j-1 occupy [0, j * keep) of last_buf: safe iff
+    // every earlier tensor of that buffer is at least as large per image (j cancels)
+    if (n < 2) return true;
+    if (last_buf == 0 && (size_t)h * w * 64 < keep) return false;                 // conv_first -> buffer A
+    for (int l = 0; l + 1 < k; ++l)
+        if (((l & 1) ? 0 : 1) == last_buf && size[l] < keep) return false;
     return true;
 }
 // decoder, images processed LAST to FIRST: image j's writes into the buffer that holds the batched layers' output must stay behind
@@ -593,6 +596,11 @@ int adain_stylize_u8(const uint8_t* frames, int n, int h, int w, const float* en
     if (!depth_maps && !(alpha >= 0.f && alpha <= 1.f)) { set_error("stylize_u8: alpha %g outside [0, 1]", alpha); return ADAIN_EINVAL; }   // test.py:75
     if (depth_maps && (!depth_h || !depth_w)) { set_error("stylize_u8: depth maps without their sizes"); return ADAIN_EINVAL; }
     if (depth_maps && !(depth_offset >= 0.f && depth_offset <= 1.f)) { set_error("stylize_u8: offset %g outside [0, 1]", depth_offset); return ADAIN_EINVAL; }   // test.py:56
+    if (depth_maps)         // every argument is checked before the first launch: an error return leaves nothing queued on the stream
+        for (int i = 0; i < n; ++i) {
+            if (!depth_maps[i]) { set_error("stylize_u8: depth map %d is null", i); return ADAIN_EINVAL; }
+            if (depth_h[i] < 1 || depth_w[i] < 1) { set_error("stylize_u8: depth map %d is %dx%d", i, depth_h[i], depth_w[i]); return ADAIN_EINVAL; }
+        }
     if (!mask) mask_n = 0;
     if (mask && ((mask_n != 1 && mask_n != n) || (mask_c != 1 && mask_c != 3) || mask_h < 1 || mask_w < 1)) {
         set_error("stylize_u8: mask [%d][%d][%d][%d] does not fit %d RGB frames", mask_n, mask_c, mask_h, mask_w, n);
@@ -624,7 +632,6 @@ int adain_stylize_u8(const uint8_t* frames, int n, int h, int w, const float* en
     RET_IF(launch_mean_std(f, 1, n, 512, hw_c, 1e-5f, c_mean, c_std, stats_ws, p.stats_ws * sizeof(float), s));
     if (depth_maps) {       // compute_stylization_strength_map per frame, then AdaIN * (1 - P) + content_f * P (test.py:66-70)
         for (int i = 0; i < n; ++i) {
-            if (!depth_maps[i]) { set_error("stylize_u8: depth map %d is null", i); return ADAIN_EINVAL; }
             RET_IF(launch_strength_map(depth_maps[i], depth_h[i], depth_w[i], p.hc, p.wc, depth_offset, depth_prominence, pmap + (size_t)i * hw_c,
                                        pmap_ws, p.pmap_ws * sizeof(float), s));
         }

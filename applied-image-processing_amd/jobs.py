@@ -537,7 +537,7 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
     out_hw          (H, W) of a finished frame, if the caller knows it: lets ``agree=False`` jobs and chunked gathers run with
                     ranks whose block is empty.
     gather_chunks   1: ONE gather when every rank has finished (after the status word: an error anywhere raises everywhere).
-                    k > 1 (needs ``out_hw``; without it the job runs as k = 1): the block is gathered in k pieces, pieces 0 .. k-2
+                    k > 1 (needs ``out_hw``: ValueError without it): the block is gathered in k pieces, pieces 0 .. k-2
                     issued asynchronously as soon as they are finished so that they overlap the rest of the compute, then the
                     status word, then the last piece.  Every rank issues every piece whatever happens to its block - a rank that
                     fails (or whose frames are not ``out_hw``) sends zero-filled pieces - so the collective sequence is the same
@@ -560,12 +560,13 @@ def stylize_frames_sharded(engine, frames, styles, *, style_of=None, alpha=0.5, 
     dev = engine.device
     gathering = gather and world > 1
     transport = None
-    chunks = max(1, int(gather_chunks)) if gathering else 1
-    if chunks > 1 and out_hw is None:
+    if int(gather_chunks) > 1 and out_hw is None:
         # Pieces are issued inside the frame loop, BEFORE the status word: a rank that fails must still take part in every one of
-        # them (with zero-filled blocks), so it has to know what a finished frame looks like without having finished one.  Without
-        # out_hw the job falls back to the single post-agreement gather - the same decision on every rank (arguments only).
-        chunks = 1
+        # them (with zero-filled blocks), so it has to know what a finished frame looks like without having finished one.  Asking
+        # for pieces without out_hw is an error, decided from the arguments alone: the same on every rank and for every world size
+        # (round 4 silently ran such a job with one end gather: no overlap and no signal).
+        raise ValueError("gather_chunks > 1 needs out_hw (the size of a finished frame): pieces are gathered before the ranks agree")
+    chunks = max(1, int(gather_chunks)) if gathering else 1
     if gathering:
         transport = sh.device_transport(torch.empty(0, dtype=torch.uint8, device=dev), group)
         if require_transport and transport != require_transport:

@@ -71,6 +71,38 @@ def device_transport(tensor, group=None):
     return "rccl" if name == "nccl" else name
 
 
+def rank_census(mine, device=None, group=None):
+    """What a multi-rank result line needs to PROVE that the device transport saw ``world`` ranks on ``world`` devices: every rank's
+    descriptor ``mine`` (a dict with at least "host" and "uuid" or "device") collected with all_gather_object, and the result of ONE
+    all_reduce(SUM) of a 1 per rank over the transport that will carry the frames (a device-resident 1 over RCCL when ``device`` is a
+    GPU of an RCCL group, a host word otherwise) - equal to the world size iff every rank took part.  Identical on every rank."""
+    world = dist.get_world_size(group)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine, group=group)
+    transport = None
+    one = torch.ones(1, dtype=torch.int32)
+    if device is not None and torch.device(device).type == "cuda":
+        transport = device_transport(torch.empty(0, dtype=torch.uint8, device=device), group)
+    if transport == "rccl":
+        one = one.to(device)                  # device tensor: rides the cuda backend (RCCL)
+    dist.all_reduce(one, group=group)
+    return {"world": world, "devices": everyone, "distinct_devices": len({(d.get("host"), d.get("uuid") or d.get("device")) for d in everyone}),
+            "transport": transport, "allreduce_of_ones": int(one.item())}
+
+
+def census_problems(census, shared_devices_allowed=False):
+    """Why a multi-rank line must NOT be reported as a multi-GPU measurement (empty list = it may): the all_reduce of ones did not
+    see every rank, or two ranks sit on one device (allowed only in a labelled single-GPU rehearsal).  The decision uses what every
+    rank holds after ``rank_census``, so all ranks reach it together (bench.py exits non-zero on every rank)."""
+    out = []
+    world = census["world"]
+    if census["allreduce_of_ones"] != world:
+        out.append(f"all_reduce of ones over the frame transport gave {census['allreduce_of_ones']}, not the world size {world}")
+    if census["distinct_devices"] != world and not shared_devices_allowed:
+        out.append(f"{world} ranks on {census['distinct_devices']} distinct device(s): one process per GPU is the contract")
+    return out
+
+
 def _status_tensor(value, device, group):
     """One word for a host-side rendezvous: a CPU tensor when the group has a CPU backend (it then rides gloo and never
     touches the GPUs), else a device tensor (a pure ``nccl`` group)."""

@@ -88,9 +88,13 @@ def self_launch():
 
     limit = float(_argv_value("--launch-timeout", "1500"))
     if "--rehearse" not in sys.argv:
-        import torch                              # device_count() only counts: it does not initialise HIP in this process
-
-        ndev = torch.cuda.device_count()
+        # counted by a throw-away child, exactly as a rank will see them: THIS process never imports torch or touches HIP
+        # (torch.cuda.device_count() falls back to hipGetDeviceCount, which initialises the runtime, when amdsmi does not import)
+        try:
+            ndev = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                                      timeout=300).stdout.strip().splitlines()[-1])
+        except (IndexError, ValueError, subprocess.TimeoutExpired):
+            ndev = 0
         if ndev < n:
             raise SystemExit(f"bench.py: --gpus {n} means {n} ranks, one per GPU, but {ndev} GPU(s) are visible here "
                              "(--rehearse runs the multi-rank path with ranks sharing a GPU, labelled as a rehearsal)")
@@ -700,6 +704,7 @@ class Ctx:
             raise SystemExit(f"bench.py: {local_world} ranks on this node but only {ndev} GPU(s) visible: one process per GPU is the "
                              "contract (RCCL rejects two ranks on one device); use --rehearse for a single-GPU rehearsal")
         self.shared_gpu = local_world > ndev
+        self.rehearse = bool(args.rehearse)
         torch.cuda.set_device(local_rank % ndev)
         self.device = torch.device("cuda", local_rank % ndev)
         self.use_dist = world > 1 or "RANK" in os.environ      # torch.distributed.run sets RANK even for one process
@@ -725,21 +730,22 @@ class Ctx:
                 "gcn_arch": getattr(props, "gcnArchName", ""), "pid": os.getpid(), "host": os.uname().nodename}
         if not self.use_dist:
             return {"world": 1, "devices": [mine], "transport": None, "launcher": "single process"}
-        everyone = [None] * self.world
-        dist.all_gather_object(everyone, mine)
-        one = torch.ones(1, dtype=torch.int32, device=self.device)
-        if self.transport == "rccl":
-            dist.all_reduce(one)                      # device tensor: rides the cuda backend (RCCL)
-        else:
-            one = one.cpu()
-            dist.all_reduce(one)
+        census = sh.rank_census(mine, None if self.transport != "rccl" else self.device)
         try:
             ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if self.transport == "rccl" else None
         except Exception as e:                        # the proof above does not depend on it
             ver = f"unavailable ({type(e).__name__})"
-        return {"world": self.world, "devices": everyone, "distinct_devices": len({(d["host"], d["uuid"] or d["device"]) for d in everyone}),
-                "transport": self.transport, "rccl": ver, "allreduce_of_ones": int(one.item()), "backend": str(dist.get_backend_config()),
-                "launcher": "bench.py self-launch" if os.environ.get("ADAIN_SELF_LAUNCHED") else "torch.distributed.run / external"}
+        census.update(transport=self.transport, rccl=ver, backend=str(dist.get_backend_config()),
+                      launcher="bench.py self-launch" if os.environ.get("ADAIN_SELF_LAUNCHED") else "torch.distributed.run / external")
+        # a line whose transport did not see every rank, or whose ranks share a device, is not a multi-GPU measurement: every rank
+        # holds the same census, so every rank stops here, non-zero, before anything is timed (a rehearsal is labelled instead)
+        problems = sh.census_problems(census, shared_devices_allowed=self.rehearse)
+        if problems:
+            if self.rank == 0:
+                print("bench.py: refusing to report a multi-GPU number: " + "; ".join(problems), file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            raise SystemExit(3)
+        return census
 
     def barrier(self):
         torch.cuda.synchronize()                      # this rank's GPU work is done ...
@@ -862,13 +868,15 @@ def main_job(args, ctx):
             result["rehearsal"] = {"ranks_share_a_gpu": ctx.shared_gpu, "note": "not a multi-GPU measurement"}
         if pcie is not None:
             result["pcie_inclusive"] = pcie
-        if world == 1 and not args.no_secondary:
+        if not args.no_secondary:              # rank 0's GPU, after the timed region (the other ranks wait in the final rendezvous)
             result["secondary"] += measure_pixel_kernels(device)
-        if world == 1 and not args.no_cpu:
+        if not args.no_cpu:                    # rank 0's host cores, after the timed region, at every N (north_star: "in the same run")
             step.run()
             torch.cuda.synchronize()
             cb, psnr, rel = cpu_baseline(step, first_u8, job_frames=[frames[k] for k in range(min(2, n_total))],
                                           job_depth=[depths[k] for k in range(min(2, n_total))] if depths is not None else None)
+            if world > 1:
+                cb["sample"] += f"; measured on rank 0 after the timed region while the other {world - 1} rank(s) wait in the final host rendezvous"
             result["cpu_baseline"] = cb
             result["psnr_db_vs_cpu"] = round(psnr, 2) if psnr != float("inf") else "inf"
             result["rel_l2_vs_cpu"] = float(f"{rel:.3e}")
@@ -1113,12 +1121,14 @@ def main():
             pdt = (time.perf_counter() - p0) / args.steps
             result["pcie_inclusive"] = {"value": round(args.batch * h * w / 1e6 / pdt, 3), "unit": "Mpixels/s",
                                         "ms_per_step": round(pdt * 1e3, 4), "what": "pinned fp32 frame H2D + forward + uint8 D2H per step"}
-        if world == 1 and not args.no_secondary:
+        if not args.no_secondary:              # rank 0's GPU, after the timed region (the other ranks wait in the final rendezvous)
             result["secondary"] += measure_pixel_kernels(device)
-        if world == 1 and not args.no_cpu:
+        if not args.no_cpu:                    # rank 0's host cores, after the timed region, at every N (north_star: "in the same run")
             out = step.run()
             torch.cuda.synchronize()
             cb, psnr, rel = cpu_baseline(step, step.u8 if args.config in (4, 5) else out)
+            if world > 1:
+                cb["sample"] += f"; measured on rank 0 after the timed region while the other {world - 1} rank(s) wait in the final host rendezvous"
             result["cpu_baseline"] = cb
             result["psnr_db_vs_cpu"] = round(psnr, 2) if psnr != float("inf") else "inf"
             result["rel_l2_vs_cpu"] = float(f"{rel:.3e}")

@@ -317,9 +317,12 @@ def test_an_error_on_one_rank_raises_on_every_rank(mode, chunks):
         assert errs[2].startswith("ValueError") and all(e.startswith("RuntimeError") for e in errs[:2]), outs
 
 
-def test_chunked_gather_without_out_hw_runs_as_one_gather():
+def test_chunked_gather_without_out_hw_is_refused():
+    """Pieces need the finished frame's size up front; round 4 downgraded such a job to one end gather without a word."""
     frames, _ = _u8_inputs(4)
-    out, info = jobs.stylize_frames_sharded(StubEngine(), frames, torch.full((1, 3, 4, 4), 0.3), sub_batch=2, gather_chunks=3)
+    with pytest.raises(ValueError, match="out_hw"):
+        jobs.stylize_frames_sharded(StubEngine(), frames, torch.full((1, 3, 4, 4), 0.3), sub_batch=2, gather_chunks=3)
+    out, info = jobs.stylize_frames_sharded(StubEngine(), frames, torch.full((1, 3, 4, 4), 0.3), sub_batch=2, gather_chunks=3, out_hw=(12, 20))
     assert out.shape[0] == 4 and info["gathers"] == 0            # (single process: nothing to gather, no piece logic either)
 
 
@@ -514,3 +517,37 @@ def test_file_sink_bounds_the_blocks_in_flight(tmp_path):
     bad.write(blocks[0], [tmp_path / "no_such_dir" / "x.png"])
     with pytest.raises(OSError):
         bad.close()
+
+
+# ---- the census a multi-rank bench line carries, and the refusal it now enforces (round 5) ---------------------------------------
+def _census_worker(rank, world, port, uuids, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        census = sh.rank_census({"rank": rank, "host": "box", "uuid": uuids[rank], "device": rank, "pid": os.getpid()})
+        outs = [None] * world
+        dist.all_gather_object(outs, (census["allreduce_of_ones"], census["distinct_devices"], [d["rank"] for d in census["devices"]],
+                                      sh.census_problems(census), sh.census_problems(census, shared_devices_allowed=True)))
+        if rank == 0:
+            q.put(outs)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("uuids,ok", [(("GPU-a", "GPU-b"), True), (("GPU-a", "GPU-a"), False)])
+def test_rank_census_refuses_two_ranks_on_one_device(uuids, ok):
+    """bench.py exits non-zero (outside --rehearse) when ``census_problems`` is non-empty: with a faked device list in which both
+    ranks report the same GPU, every rank must reach the same refusal; distinct devices and a full all_reduce pass."""
+    outs = _run(_census_worker, 2, (uuids,))
+    assert len({repr(o) for o in outs}) == 1, outs                # identical on every rank: all ranks stop (or go on) together
+    ones, distinct, order, problems, rehearsal = outs[0]
+    assert ones == 2 and order == [0, 1] and distinct == (2 if ok else 1)
+    assert (problems == []) is ok and rehearsal == []
+    if not ok:
+        assert "one process per GPU" in problems[0]
+
+
+def test_census_problems_flags_a_short_allreduce():
+    census = {"world": 4, "allreduce_of_ones": 3, "distinct_devices": 4, "devices": []}
+    assert len(sh.census_problems(census)) == 1 and "not the world size 4" in sh.census_problems(census)[0]
+    assert sh.census_problems(dict(census, allreduce_of_ones=4)) == []

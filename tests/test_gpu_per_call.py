@@ -140,6 +140,13 @@ def test_style_cache_follows_the_weights_and_the_arguments(t, ckpt, tmp_path):
     assert t.STYLE_ENCODES[0] - e0 == 3 and b == a
     t.adain_inference(c, s, style_size=48, file_name="d", **kw)
     assert t.STYLE_ENCODES[0] - e0 == 3
+    # a style object edited IN PLACE is another style (round-4 advisor finding: the key was the object's identity alone)
+    e0 = t.STYLE_ENCODES[0]
+    before = t.adain_inference(c, s, style_size=48, file_name="m0", **kw).read_bytes()
+    s.paste(Image.fromarray(u8img(982, 20, 30)), (10, 12))
+    after = t.adain_inference(c, s, style_size=48, file_name="m1", **kw).read_bytes()
+    fresh = t.adain_inference(c, s.copy(), style_size=48, file_name="m2", **kw).read_bytes()
+    assert t.STYLE_ENCODES[0] - e0 == 2 and after != before and after == fresh
     # preserve_color changes the style per content image (coral): never cached, call-by-call path
     e0 = t.STYLE_ENCODES[0]
     t.adain_inference(c, s, style_size=48, file_name="e", preserve_color=True, **kw)

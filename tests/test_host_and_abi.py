@@ -160,6 +160,27 @@ def test_test_transform_semantics():
     assert t.test_transform(0, False)(gray).shape == (1, 40, 60)
 
 
+def test_style_object_fingerprint_moves_with_in_place_edits():
+    """The style cache keys a PIL object by identity AND by a fingerprint of its pixels (AdaIN/test.py:_pixel_fingerprint): any
+    in-place edit - one pixel, a swap of two pixels, a paste - must move it; an untouched image keeps it."""
+    from PIL import Image
+    from applied_image_processing_amd.AdaIN import test as t
+
+    base = (synth.image(6, 1, 70, 93, c=4)[0].transpose(1, 2, 0) * 255).astype(np.uint8)
+    for mode, a in (("RGB", base[..., :3]), ("RGBA", base), ("L", base[..., 0])):
+        img = Image.fromarray(np.ascontiguousarray(a), mode)
+        f0 = t._pixel_fingerprint(img)
+        assert f0 is not None and f0 == t._pixel_fingerprint(img) == t._pixel_fingerprint(img.copy())
+        p, q = img.getpixel((3, 4)), img.getpixel((60, 50))
+        assert p != q
+        img.putpixel((3, 4), q)
+        f1 = t._pixel_fingerprint(img)
+        img.putpixel((60, 50), p)                         # now the two pixels are swapped: same histogram, another image
+        f2 = t._pixel_fingerprint(img)
+        img.paste(img.crop((0, 0, 20, 20)), (40, 30))
+        assert len({f0, f1, f2, t._pixel_fingerprint(img)}) == 4, mode
+
+
 def test_shard_ranges():
     assert sh.shard_counts(300, 8) == [38, 38, 38, 38, 37, 37, 37, 37]
     assert sh.shard_counts(512, 8) == [64] * 8
