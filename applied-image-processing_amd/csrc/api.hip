@@ -403,6 +403,13 @@ int adain_encode_u8(const uint8_t* image, float* feat, const float* packed, void
     return encode_impl(1, &img, 1, &feat, &n, &h, &w, packed, workspace, ws_bytes, ev, stream);
 }
 
+int adain_encode_relu1_1(const void* image, int is_u8, float* relu1_1, const float* packed, int n, int h, int w, adain_stream_t stream) {
+    if (!image || !relu1_1 || !packed) { set_error("encode_relu1_1: null pointer"); return ADAIN_EINVAL; }
+    if (n < 1 || h < 2 || w < 2) { set_error("encode_relu1_1: image %dx%d too small (the reflection pad needs h, w >= 2)", h, w); return ADAIN_EINVAL; }
+    const Offsets f = enc_offsets();
+    return launch_conv_first(image, is_u8 ? 1 : 0, relu1_1, packed, packed + f.first_b, n, h, w, (hipStream_t)stream);
+}
+
 size_t adain_decode_workspace_bytes(int n, int hc, int wc) {
     if (n < 1 || hc < 1 || wc < 1) return 0;
     return (align64((size_t)n * hc * wc * 1024) + align64((size_t)n * hc * wc * 4096)) * sizeof(float);

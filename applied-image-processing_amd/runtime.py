@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_PKG, "libadain_hip.so")
 DIAG_LIB_PATH = os.path.join(_PKG, "libadain_hip_diag.so")
 
 SRC_DIRECT, SRC_UP2X, SRC_POOL2 = 0, 1, 2
-ABI_VERSION = 2          # ADAIN_ABI_VERSION of include/adain_hip.h this binding was written against
+ABI_VERSION = 3          # ADAIN_ABI_VERSION of include/adain_hip.h this binding was written against
 
 _c_int, _c_float, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 _PP = ctypes.POINTER(ctypes.c_void_p)
@@ -35,6 +35,7 @@ SIGNATURES = {
     "adain_encode_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "adain_encode": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_int, _c_int, _PP, _c_void_p]),
     "adain_encode_u8": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_int, _c_int, _PP, _c_void_p]),
+    "adain_encode_relu1_1": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_encode_multi_workspace_bytes": (_c_size_t, [_c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "adain_encode_multi": (_c_int, [_c_int, _PP, _PP, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), _c_void_p,
                                     _c_void_p, _c_size_t, _PP, _c_void_p]),
@@ -245,6 +246,20 @@ def encode_u8(frames_u8, packed, events=None):
         _check(lib().adain_encode_u8(x.data_ptr(), feat.data_ptr(), packed.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, ev,
                                      _stream()), "adain_encode_u8")
     return feat
+
+
+def encode_relu1_1(image, packed):
+    """vgg[:4] (conv0 -> pad -> conv1_1 -> relu, net.py:39-42) as the one folded layer the encoder starts with: image NCHW float
+    [n,3,h,w] or decoded uint8 frames [n,h,w,3] -> relu1_1 NHWC [n,h,w,64]."""
+    u8 = isinstance(image, torch.Tensor) and image.dtype == torch.uint8
+    x = _dev(image, "image", torch.uint8 if u8 else torch.float32)
+    if x.dim() != 4 or (x.shape[3] if u8 else x.shape[1]) != 3:
+        raise AdainHipError(f"encode_relu1_1: expected float [n,3,h,w] or uint8 [n,h,w,3], got {tuple(x.shape)}")
+    n, h, w = (x.shape[0], x.shape[1], x.shape[2]) if u8 else (x.shape[0], x.shape[2], x.shape[3])
+    out = torch.empty((n, h, w, 64), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().adain_encode_relu1_1(x.data_ptr(), 1 if u8 else 0, out.data_ptr(), packed.data_ptr(), n, h, w, _stream()), "adain_encode_relu1_1")
+    return out
 
 
 def encode_multi(images, packed, events=None):

@@ -154,3 +154,114 @@ def to_torch(sd):
     import torch
 
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+# ---- a second weight set: "trained-like" statistics -------------------------------------------------------------------------------
+# The checkpoint the reference really loads (test.py:183-185; an LFS pointer here) is the "normalised" VGG-19 of the AdaIN release:
+# conv0 carries Caffe-style preprocessing (x255, RGB -> BGR, mean subtraction: pixel values near +-100 enter conv1_1), filters have
+# non-zero means and a share of zero-sum (edge-detector) filters, and every channel was rescaled so that its post-ReLU activation
+# averages 1 over images - activations with a large DC part instead of the zero-mean O(1) noise the Kaiming set produces.  That
+# regime is what stresses the folded first layer (conv0 into conv1_1: the x255 terms cancel against a folded bias of order 100 x
+# sum|w|) and the F(4,3) x F(2,3) transforms (a DC of 1 under zero-sum filters).  This set rebuilds it from the integer PRNG:
+#   conv0            W = 255 * [[0,0,1],[0,1,0],[1,0,0]], b = (-103.939, -116.779, -123.68)
+#   every 3x3 conv   Kaiming-uniform base; output channel o is, by o % 4: 0 a "blob" filter (every weight + 6 / fan_in: a DC gain of 6
+#                    on mean-1 inputs), 1 a spatial edge detector (each 3x3 slice minus its own mean: zero sum per input channel),
+#                    2 an opponent filter (the whole filter minus its mean), 3 the base minus 1 / fan_in (sparse activations);
+#   normalisation    layer by layer, channel o of (w, b) is multiplied by 1 / (its post-ReLU mean over two calibration images), as the
+#                    normalised VGG was made; the decoder the same way on AdaIN(content, style) features, its last layer scaled to
+#                    an image of mean 0.5 / std 0.22 per colour.
+# The calibration forward runs in float64 and every scale is rounded to 9 significant bits before it multiplies the float32 weights
+# (one correctly rounded multiply): last-bit differences between machines' float64 convolutions cannot move a scale, so the
+# container that writes tests/golden/case_g.npz and the GPU box rebuild the same weights bit for bit.
+_TL_CACHE = {}
+
+
+def _round_bits(x, bits=9):
+    """float64 array rounded to ``bits`` significant bits."""
+    m, e = np.frexp(np.asarray(x, dtype=np.float64))
+    return np.ldexp(np.round(m * (1 << bits)) / (1 << bits), e)
+
+
+def _calibration_images(seed):
+    """Two 64 x 64 RGB images in [0, 1): three quarters uniform noise - what the parity tests and the bench feed, so the channel means
+    sit near 1 THERE - and one quarter smooth field."""
+    out = []
+    for k in range(2):
+        sm = smooth_depth(seed * 7919 + 31 + k, 64, 64).astype(np.float64) / 1000.0
+        rgb = np.stack([sm, sm[::-1, :], sm[:, ::-1]])
+        out.append(0.25 * rgb + 0.75 * image(seed * 7919 + 41 + k, 1, 64, 64)[0].astype(np.float64))
+    return np.stack(out)
+
+
+def _shaped_filter(seed, net_id, idx, cin, cout):
+    w, b = _conv_params(seed, net_id + 10, idx, cin, cout, 3)
+    fan_in = cin * 9
+    w = w.copy()
+    w[0::4] += np.float32(6.0 / fan_in)
+    w[1::4] -= w[1::4].mean(axis=(2, 3), keepdims=True, dtype=np.float32)
+    w[2::4] -= w[2::4].mean(axis=(1, 2, 3), keepdims=True, dtype=np.float32)
+    w[3::4] -= np.float32(1.0 / fan_in)
+    return w, (b * np.float32(2.0)).astype(np.float32)
+
+
+def trained_like_state_dicts(seed=0):
+    """``(vgg_state_dict (all 17 convs), decoder_state_dict)`` as numpy, reference key layout: see the block comment above."""
+    if seed in _TL_CACHE:
+        return _TL_CACHE[seed]
+    import torch
+    import torch.nn.functional as F
+
+    def conv(x, w, b):
+        return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), torch.from_numpy(w.astype(np.float64)), torch.from_numpy(b.astype(np.float64)))
+
+    def normalised(x, w, b):
+        """(w, b) with every output channel scaled to a post-ReLU mean of 1 on x."""
+        mean = F.relu(conv(x, w, b)).mean(dim=(0, 2, 3)).numpy()
+        s = _round_bits(1.0 / np.maximum(mean, 0.25 * np.median(mean))).astype(np.float32)     # (rarely firing channels: gain capped)
+        return w * s[:, None, None, None], b * s
+
+    nthreads = torch.get_num_threads()
+    vgg = vgg_state_dict(seed, full=True)                   # the convs behind relu4_1 stay Kaiming: net.vgg[:31] never runs them
+    vgg["0.weight"] = (np.float32(255.0) * np.eye(3, dtype=np.float32)[::-1]).reshape(3, 3, 1, 1).copy()
+    vgg["0.bias"] = np.array([-103.939, -116.779, -123.68], dtype=np.float32)
+    x = torch.from_numpy(_calibration_images(seed))
+    x = F.conv2d(x, torch.from_numpy(vgg["0.weight"].astype(np.float64)), torch.from_numpy(vgg["0.bias"].astype(np.float64)))
+    for i, m in enumerate(arch.VGG_MODULES[: arch.ENCODER_CUT]):
+        if m[0] == "pool":
+            x = F.max_pool2d(x, 2, 2, 0, ceil_mode=True)
+        elif m[0] == "conv" and m[3] == 3:
+            w, b = normalised(x, *_shaped_filter(seed, 1, i, m[1], m[2]))
+            vgg[f"{i}.weight"], vgg[f"{i}.bias"] = w, b
+            x = F.relu(conv(x, w, b))
+    # decoder: calibrated on AdaIN(content_f, style_f) of the two images (function.py:15-23)
+    mu, sd = x.mean(dim=(2, 3), keepdim=True), (x.var(dim=(2, 3), keepdim=True) + 1e-5).sqrt()
+    x = (x - mu) / sd * sd.flip(0) + mu.flip(0)
+    dec = {}
+    convs = arch.conv_indices(arch.DECODER_MODULES)
+    for i, m in enumerate(arch.DECODER_MODULES):
+        if m[0] == "up":
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+        elif m[0] == "conv":
+            w, b = _shaped_filter(seed, 2, i, m[1], m[2])
+            if i != convs[-1]:
+                w, b = normalised(x, w, b)
+                x = F.relu(conv(x, w, b))
+            else:                                           # 64 -> 3, no ReLU: an image of mean 0.5, std 0.22 per colour
+                y = conv(x, w, np.zeros_like(b))
+                s = _round_bits(0.22 / y.std(dim=(0, 2, 3)).numpy()).astype(np.float32)
+                w = w * s[:, None, None, None]
+                b = _round_bits(0.5 - s.astype(np.float64) * y.mean(dim=(0, 2, 3)).numpy()).astype(np.float32)
+            dec[f"{i}.weight"], dec[f"{i}.bias"] = w, b
+    torch.set_num_threads(nthreads)
+    _TL_CACHE[seed] = (vgg, dec)
+    return vgg, dec
+
+
+def state_dicts(kind="kaiming", seed=0):
+    """``(vgg_state_dict (full), decoder_state_dict)`` of a named weight set: "kaiming" (zero-mean, O(1) activations: the set every
+    round-1..4 fixture uses) or "trained-like" (see above)."""
+    if kind == "kaiming":
+        return vgg_state_dict(seed, full=True), decoder_state_dict(seed)
+    if kind == "trained-like":
+        return trained_like_state_dicts(seed)
+    raise ValueError(f"unknown weight set {kind!r}")

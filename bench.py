@@ -263,8 +263,12 @@ def synth_frame(config, index, h, w):
     return x
 
 
+WEIGHT_SET = "kaiming"       # --weights: "kaiming" (zero-mean Kaiming-uniform, O(1) activations) or "trained-like" (synth.trained_like_state_dicts)
+
+
 def synth_weights():
-    return synth.to_torch(synth.vgg_state_dict(0, full=False)), synth.to_torch(synth.decoder_state_dict(0))
+    vgg, dec = synth.state_dicts(WEIGHT_SET, 0)
+    return synth.to_torch(vgg), synth.to_torch(dec)
 
 
 JOB_FRAMES = {4: 512, 5: 300}        # BASELINE.json configs[3] / configs[4]
@@ -665,6 +669,9 @@ def parse_args():
                          "BASELINE step; --steps = calls (default 20)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="bare `--gpus N` launch: seconds after which the rank processes are stopped")
     ap.add_argument("--n1-value", type=float, default=0.0, help="--job: the 1-GPU value of the same job, to report efficiency_vs_n1")
+    ap.add_argument("--weights", choices=["kaiming", "trained-like"], default="kaiming",
+                    help="the seeded weight set: zero-mean Kaiming (default; every round-1..4 number) or the trained-like statistics of "
+                         "synth.trained_like_state_dicts (the regime of the checkpoint the reference loads; same kernels, same flops)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1080p pixel-kernel bandwidth table")
     ap.add_argument("--pcie", action="store_true", help="also report the rate with the frame crossing PCIe both ways (never `value`)")
@@ -773,7 +780,9 @@ def base_result(args, ctx, value, ms, workload, parallelism, scaling):
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload + ", fp32, seeded synthetic weights (reference architecture)", "parallelism": parallelism},
+        "config": {"workload": workload + ", fp32, seeded synthetic weights (reference architecture"
+                               + (")" if WEIGHT_SET == "kaiming" else "; TRAINED-LIKE statistics: Caffe-style conv0, non-zero-mean / zero-sum filters, "
+                                                                      "channels normalised to a post-ReLU mean near 1)"), "parallelism": parallelism},
     }
 
 
@@ -903,7 +912,7 @@ def main_per_call(args, ctx):
     h, w = ((270, 480) if mode == "video" else (800, 800)) if not args.size else (args.size, args.size)     # the callers' own shapes
     csize = 256 if mode == "video" else 512
     root = tempfile.mkdtemp(prefix="adain_per_call_")
-    vgg_sd, dec_sd = synth.to_torch(synth.vgg_state_dict(0, full=True)), synth.to_torch(synth.decoder_state_dict(0))
+    vgg_sd, dec_sd = synth_weights()
     torch.save(vgg_sd, os.path.join(root, "vgg.pth"))
     torch.save(dec_sd, os.path.join(root, "dec.pth"))
     ck = dict(vgg_str=os.path.join(root, "vgg.pth"), decoder_str=os.path.join(root, "dec.pth"))
@@ -1015,7 +1024,9 @@ def emit(result):
 
 
 def main():
+    global WEIGHT_SET
     args = parse_args()
+    WEIGHT_SET = args.weights
     claim_stdout()
     ctx = Ctx(args)
     if args.per_call:

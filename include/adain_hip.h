@@ -27,8 +27,9 @@ extern "C" {
 #endif
 
 /* 2: adain_encode_u8, adain_u8_to_f32 and adain_stylize_u8* added; the direct / F(2x2,3x3) single-layer entry points moved to
- * the diagnostic library (include/adain_hip_diag.h); adain_conv3x3_wino accepts form 5 only.  Version 1 was never frozen. */
-#define ADAIN_ABI_VERSION 2
+ * the diagnostic library (include/adain_hip_diag.h); adain_conv3x3_wino accepts form 5 only.  Version 1 was never frozen.
+ * 3: adain_encode_relu1_1 and the uint8 Pillow-exact resize (adain_resize_pil_bilinear_u8*) added; nothing removed or changed. */
+#define ADAIN_ABI_VERSION 3
 #define ADAIN_OK 0
 #define ADAIN_EINVAL (-1)  /* bad argument / unsupported shape */
 #define ADAIN_ELAUNCH (-2) /* HIP reported a launch error */
@@ -72,6 +73,14 @@ ADAIN_API int adain_encode(const float* image_nchw, float* feat_nhwc, const floa
  * bit-identical to adain_encode(ToTensor(image)) while the frame crosses PCIe and HBM as 3 bytes per pixel instead of 12. */
 ADAIN_API int adain_encode_u8(const uint8_t* image_nhwc_u8, float* feat_nhwc, const float* packed, void* workspace,
                     size_t workspace_bytes, int n, int h, int w, void* const* layer_events, adain_stream_t stream);
+
+/* The encoder's FIRST fused layer alone: vgg[:4] = conv0 (1x1, the checkpoint's Caffe-style preprocessing: x255, channel swap,
+ * mean subtraction) -> ReflectionPad -> conv1_1 -> ReLU (net.py:39-42), which this library computes as ONE layer with conv0 folded
+ * into conv1_1's weights and bias.  image: NCHW float [n][3][h][w], or (is_u8) HWC uint8 [n][h][w][3] with ToTensor inside;
+ * relu1_1: NHWC [n][h][w][64].  For parity checks of the fold at trained-checkpoint magnitudes (tests/golden/case_g.npz) and as
+ * the first of the four taps AdaIN's own loss uses (net.py:110-117, enc_1); adain_encode* run the same kernel as their first launch. */
+ADAIN_API int adain_encode_relu1_1(const void* image, int is_u8, float* relu1_1_nhwc, const float* packed, int n, int h, int w,
+                         adain_stream_t stream);
 
 /* The same encoder over `count` (1..4) image batches of different sizes in ONE pass: the content batch and the style image
  * of a style_transfer call go through the same vgg (test.py:57,63 / :76-77).  Results are bit-identical to one adain_encode

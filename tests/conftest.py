@@ -23,6 +23,16 @@ def weights():
     return synth.to_torch(synth.vgg_state_dict(0, full=False)), synth.to_torch(synth.decoder_state_dict(0))
 
 
+@pytest.fixture(scope="session")
+def weights_tl():
+    """The TRAINED-LIKE weight set (synth.trained_like_state_dicts: Caffe-style conv0, non-zero-mean / zero-sum filters, channels
+    normalised to a post-ReLU mean near 1) as torch CPU state_dicts; the encoder with all 17 convs (a strict load_state_dict works)."""
+    import applied_image_processing_amd.synth as synth
+
+    vgg, dec = synth.trained_like_state_dicts(0)
+    return synth.to_torch(vgg), synth.to_torch(dec)
+
+
 def golden(name):
     import numpy as np
 

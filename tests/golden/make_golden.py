@@ -39,6 +39,50 @@ def localized_inputs():
     return np.maximum(a, 1) * m[..., None], np.maximum(b, 1) * (1 - m)[..., None]
 
 
+def case_g(fn, net, test):
+    """Case G (round 5): the same reference code with the TRAINED-LIKE weight set (synth.trained_like_state_dicts: Caffe-style conv0
+    - x255, channel swap, biases near -104 ... -124 -, non-zero-mean and zero-sum filters, channels normalised to a post-ReLU mean
+    near 1: the statistics of the checkpoint the reference really loads, test.py:183-185).  Content frames are decoded-image-like
+    (uint8 / 255, so the float and the uint8 entry points see the same values); relu1_1 (net.vgg[:4]: conv0 -> pad -> conv1_1 ->
+    relu, what this repo computes in ONE folded layer), relu4_1, statistics, AdaIN, alpha and depth-aware outputs at 64 x 64 and
+    at an odd size.  ``*_f64`` arrays are the same reference modules run in float64 (``.double()``), rounded to float32: the yardstick
+    that tells fp32 rounding noise of the reference itself from an error of the path under test."""
+    vgg_sd, dec_sd = synth.trained_like_state_dicts(WEIGHT_SEED)
+    net.vgg.load_state_dict(synth.to_torch(vgg_sd))
+    net.decoder.load_state_dict(synth.to_torch(dec_sd))
+    net.vgg.eval()
+    net.decoder.eval()
+    vgg = nn.Sequential(*list(net.vgg.children())[:31])
+    first = nn.Sequential(*list(net.vgg.children())[:4])
+    dec = net.decoder
+    arrays = {}
+
+    def u8_image(seed, h, w):
+        return (synth.image(seed, 1, h, w)[0].transpose(1, 2, 0) * np.float32(255)).astype(np.uint8)
+
+    def run(tag, cu8, s, depth, dtype):
+        sfx = "" if dtype == torch.float32 else "_f64"
+        c = T(cu8.transpose(2, 0, 1).copy()).float().div(255).unsqueeze(0).to(dtype)      # ToTensor (test.py:22), then the cast
+        s = s.to(dtype)
+        cf, sf = vgg(c), vgg(s)
+        mean, std = fn.calc_mean_std(cf)
+        res = dict(relu1_1=first(c), content_f=cf, style_f=sf, mean=mean, std=std, adain=fn.adaptive_instance_normalization(cf, sf),
+                   out_a05=test.style_transfer_simple(vgg, dec, c, s, 0.5), out_a10=test.style_transfer_simple(vgg, dec, c, s, 1.0),
+                   out_depth=test.style_transfer(vgg, dec, c, s, depth.to(dtype), 1.0, 0.15, 20))
+        for k, v in res.items():
+            arrays[f"{tag}_{k}{sfx}"] = v.float().numpy()
+
+    with torch.no_grad():
+        for dtype in (torch.float32, torch.float64):
+            net.vgg.to(dtype)
+            net.decoder.to(dtype)
+            run("sq", u8_image(61, 64, 64), T(synth.image(62, 1, 48, 80)), T(synth.smooth_depth(65, 64, 64)), dtype)
+            run("odd", u8_image(63, 45, 67), T(synth.image(64, 1, 50, 38)), T(synth.smooth_depth(66, 90, 134)), dtype)
+        net.vgg.float()
+        net.decoder.float()
+    np.savez_compressed(os.path.join(OUT, "case_g.npz"), meta=np.array([61, 64, 64, 62, 48, 80, 65, 63, 45, 67, 64, 50, 38, 66, 90, 134]), **arrays)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -146,6 +190,8 @@ def main():
         out_f = test.style_transfer_simple(vgg, dec, c, s, 0.5)
     np.savez_compressed(os.path.join(OUT, "case_f.npz"), content_u8=cu8, style_u8=su8, out=out_f.numpy().astype(np.float32),
                         meta=np.array([256, 256, 256, 341]))
+
+    case_g(fn, net, test)
 
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -50,7 +50,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     # -fvisibility=hidden: the C ABI is ALL the code the product library exports (no C++ launchers, no helper functions)
     assert _exported_functions(rt.LIB_PATH) == declared
     assert not hasattr(lib, "adain_conv3x3") and not hasattr(lib, "adain_debug_set_conv_stamp_buffer")
-    assert lib.adain_abi_version() == rt.ABI_VERSION == 2
+    assert lib.adain_abi_version() == rt.ABI_VERSION == 3
     assert lib.adain_encoder_packed_floats() > 3_500_000 and lib.adain_decoder_packed_floats() > 3_500_000
     hc, wc = ctypes.c_int(), ctypes.c_int()
     lib.adain_encoded_size(45, 67, ctypes.byref(hc), ctypes.byref(wc))
@@ -62,7 +62,7 @@ def test_diagnostic_library_exports_both_headers(diag_lib):
     both = sorted(set(_declared("adain_hip.h")) | set(_declared("adain_hip_diag.h")))
     assert _exported_functions(diag_lib.LIB_PATH) == both
     assert sorted(set(diag_lib.SIGNATURES) | set(diag_lib.DIAG_SIGNATURES)) == both
-    assert diag_lib.is_diag() and diag_lib.lib().adain_abi_version() == 2
+    assert diag_lib.is_diag() and diag_lib.lib().adain_abi_version() == 3
 
 
 def test_product_library_ignores_the_environment(monkeypatch):

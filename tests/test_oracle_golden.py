@@ -247,3 +247,70 @@ def test_case_e_localized_colour_transfer_host_path():
     content = np.maximum(fg, bg)
     comb = L.combine_localized(content, bg, m)
     assert comb.dtype == np.uint8 and np.array_equal(comb[m == 1], bg[m == 1])
+
+
+# ---- case G (round 5): the trained-like weight set through the unmodified reference ------------------------------------------------
+def g_inputs(tag):
+    """(content uint8 HWC, content float NCHW = ToTensor of it, style, depth) of case G's two cases, rebuilt from the seeds."""
+    seed, h, w, sseed, hs, ws, dseed, dh, dw = {"sq": (61, 64, 64, 62, 48, 80, 65, 64, 64), "odd": (63, 45, 67, 64, 50, 38, 66, 90, 134)}[tag]
+    cu8 = (synth.image(seed, 1, h, w)[0].transpose(1, 2, 0) * np.float32(255)).astype(np.uint8)
+    c = T(cu8.transpose(2, 0, 1).copy()).float().div(255).unsqueeze(0)
+    return cu8, c, T(synth.image(sseed, 1, hs, ws)), T(synth.smooth_depth(dseed, dh, dw))
+
+
+def rel_l2(a, b):
+    a = a.numpy() if torch.is_tensor(a) else a
+    return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
+
+
+def test_trained_like_weights_have_the_statistics_they_claim(weights_tl):
+    """conv0 = x255 channel swap with the Caffe means; zero-sum filters sum to zero; post-ReLU channel means sit near 1 with a
+    large DC part on the blob channels - on an image the calibration never saw."""
+    vgg, dec = weights_tl
+    assert vgg["0.weight"].flatten().tolist() == [0, 0, 255, 0, 255, 0, 255, 0, 0]
+    np.testing.assert_allclose(vgg["0.bias"].numpy(), [-103.939, -116.779, -123.68], rtol=1e-7)
+    assert len(vgg) == 34 and len(dec) == 18                    # 17 + 9 convs: strict load_state_dict into the reference modules
+    for k in ("5.weight", "16.weight", "29.weight"):
+        w = vgg[k]
+        assert float(w[1::4].sum(dim=(2, 3)).abs().max()) < 1e-5 * float(w.abs().max()) * 9         # spatial edge detectors: every 3x3 slice
+        assert float(w[2::4].sum(dim=(1, 2, 3)).abs().max()) < 1e-4 * float(w.abs().max()) * w[0].numel() ** 0.5
+        assert float(w[0::4].mean()) > 0
+    _, c, _, _ = g_inputs("sq")
+    with torch.no_grad():
+        x = torch.nn.functional.conv2d(c, vgg["0.weight"], vgg["0.bias"])
+        assert float(x.min()) < -100 and float(x.max()) > 100                                        # what conv1_1 sees
+        f = O.encode(vgg, c)
+    per_channel = f.mean(dim=(0, 2, 3))
+    assert 0.8 < float(per_channel.median()) < 2.0 and 0.8 < float(f.mean()) < 2.0
+    blob = f[0, 0::4].reshape(128, -1)
+    assert float((blob.mean(dim=1) / blob.std(dim=1)).median()) > 2.0                                # large DC
+    # bit-reproducible: a second build gives the same bits (the cache is bypassed)
+    synth._TL_CACHE.clear()
+    again = synth.trained_like_state_dicts(0)
+    assert all(np.array_equal(again[0][k], vgg[k].numpy()) for k in vgg) and all(np.array_equal(again[1][k], dec[k].numpy()) for k in dec)
+
+
+def test_case_g_trained_like_weights(weights_tl):
+    """The oracle on the trained-like set against the reference's own outputs (same op graph, same CPU backend), and the noise
+    floor of the reference's fp32 arithmetic itself against its float64 run: with these statistics the reference is 2-3e-5 (relative
+    L2) from float64 on the outputs - 20 times its distance with the Kaiming set - which is the yardstick of the GPU tests."""
+    vgg, dec = weights_tl
+    g = golden("case_g.npz")
+    for tag in ("sq", "odd"):
+        _, c, s, depth = g_inputs(tag)
+        with torch.no_grad():
+            first = torch.relu(O._conv3x3_reflect(torch.nn.functional.conv2d(c, vgg["0.weight"], vgg["0.bias"]), vgg["2.weight"], vgg["2.bias"]))
+            close(first, g[f"{tag}_relu1_1"], 1e-5, 1e-5)
+            cf, sf = O.encode(vgg, c), O.encode(vgg, s)
+            close(cf, g[f"{tag}_content_f"], 1e-4, 1e-4)
+            close(sf, g[f"{tag}_style_f"], 1e-4, 1e-4)
+            m, sd = O.calc_mean_std(cf)
+            close(m, g[f"{tag}_mean"], 1e-4, 1e-5)
+            close(sd, g[f"{tag}_std"], 1e-4, 1e-5)
+            close(O.adaptive_instance_normalization(cf, sf), g[f"{tag}_adain"], 1e-3, 1e-3)
+            for key, out in (("out_a05", O.style_transfer_simple(vgg, dec, c, s, 0.5)), ("out_a10", O.style_transfer_simple(vgg, dec, c, s, 1.0)),
+                             ("out_depth", O.style_transfer(vgg, dec, c, s, depth, 1.0, 0.15, 20))):
+                assert rel_l2(out, g[f"{tag}_{key}"]) < 2e-5, (tag, key)
+        for key in ("relu1_1", "content_f", "adain", "out_a05", "out_a10", "out_depth"):
+            floor = rel_l2(g[f"{tag}_{key}"], g[f"{tag}_{key}_f64"])
+            assert floor < (2e-7 if key == "relu1_1" else 1e-5 if key in ("content_f", "adain") else 6e-5), (tag, key, floor)
