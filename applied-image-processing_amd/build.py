@@ -14,7 +14,7 @@ LIB = os.path.join(PKG, "libadain_hip.so")
 DIAG_LIB = os.path.join(PKG, "libadain_hip_diag.so")     # -DADAIN_DIAG: env tuning switches, stamp / timing-only kernels (tools/ only)
 # The product library holds only what its schedules launch; the direct implicit-GEMM family and the F(2x2,3x3) Winograd families
 # (rounds 1-2, A/B baselines with their own tests) are compiled into the diagnostic library only.
-SOURCES = ["conv_edge.hip", "conv_wino4.hip", "stats.hip", "pixel.hip", "api.hip"]
+SOURCES = ["conv_edge.hip", "conv_wino4.hip", "stats.hip", "pixel.hip", "resample.hip", "api.hip"]
 DIAG_SOURCES = ["conv_direct.hip", "conv_wino.hip", "conv_wino3.hip"]
 # -fvisibility=hidden: the shared library exports the C ABI of include/adain_hip.h (ADAIN_API) and nothing else
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]

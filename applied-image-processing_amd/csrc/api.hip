@@ -536,6 +536,15 @@ int adain_resize_area_u8(const uint8_t* in, uint8_t* out, int n, int hi, int wi,
     if (!in || !out) { set_error("resize_area_u8: null pointer"); return ADAIN_EINVAL; }
     return launch_resize_area_u8(in, out, n, hi, wi, c, ho, wo, (hipStream_t)stream);
 }
+size_t adain_resize_pil_bilinear_u8_workspace_bytes(int hi, int wi, int ho, int wo) { return resize_pil_workspace_bytes(hi, wi, ho, wo); }
+
+int adain_resize_pil_bilinear_u8(const uint8_t* in, int pixel_bytes, int n, int hi, int wi, uint8_t* out, int ho, int wo, int crop_y0, int crop_x0,
+                                 int crop_h, int crop_w, void* workspace, size_t ws_bytes, adain_stream_t stream) {
+    if (!in || !out) { set_error("resize_pil_bilinear_u8: null pointer"); return ADAIN_EINVAL; }
+    return launch_resize_pil_bilinear_u8(in, pixel_bytes, n, hi, wi, out, ho, wo, crop_y0, crop_x0, crop_h, crop_w, workspace, ws_bytes,
+                                         (hipStream_t)stream);
+}
+
 int adain_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, adain_stream_t stream) {
     if (!in || !out) { set_error("nhwc_to_nchw: null pointer"); return ADAIN_EINVAL; }
     return launch_nhwc_to_nchw(in, out, n, c, hw, (hipStream_t)stream);

@@ -130,6 +130,11 @@ int launch_mask_to_f32(const uint8_t* in, float* out, size_t total, hipStream_t 
 int launch_nhwc_to_nchw(const float* in, float* out, int n, int c, int hw, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, float* out, int n, int c, int hw, hipStream_t s);
 
+// resample.hip: PIL.Image.resize(size, BILINEAR) on uint8 RGB, bit-exact (Pillow's ImagingResample)
+size_t resize_pil_workspace_bytes(int hi, int wi, int ho, int wo);
+int launch_resize_pil_bilinear_u8(const uint8_t* in, int pixel_bytes, int n, int hi, int wi, uint8_t* out, int ho, int wo, int y0, int x0, int ch,
+                                  int cw, void* workspace, size_t ws_bytes, hipStream_t s);
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

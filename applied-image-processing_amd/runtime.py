@@ -56,6 +56,8 @@ SIGNATURES = {
     "adain_u8_to_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "adain_warp_blend_u8": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p]),
     "adain_resize_area_u8": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 6 + [_c_void_p]),
+    "adain_resize_pil_bilinear_u8_workspace_bytes": (_c_size_t, [_c_int] * 4),
+    "adain_resize_pil_bilinear_u8": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p] + [_c_int] * 6 + [_c_void_p, _c_size_t, _c_void_p]),
     "adain_stylize_u8_workspace_bytes": (_c_size_t, [_c_int] * 9),
     "adain_stylize_u8_out_size": (None, [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "adain_stylize_u8": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_float, _PP,
@@ -520,6 +522,27 @@ def resize_area_u8(frames, dsize):
     with torch.cuda.device(frames.device):
         _check(lib().adain_resize_area_u8(frames.data_ptr(), out.data_ptr(), n, hi, wi, c, ho, wo, _stream()), "adain_resize_area_u8")
     return out[0] if single else out
+
+
+def resize_pil_bilinear_u8(frames, size, crop=None, out=None):
+    """``PIL.Image.resize(size, BILINEAR)`` of uint8 images on the device, bit for bit (test.py:16-24's Resize on a PIL image).
+    frames: uint8 [n,h,w,3] (packed RGB) or [n,h,w,4] (Pillow's RGBX storage); ``size`` = (width, height) as PIL takes it;
+    ``crop`` = (top, left, height, width) window of the result (CenterCrop), default all of it.  Returns packed RGB uint8 [n,ch,cw,3]."""
+    x = _dev(frames, "frames", torch.uint8)
+    if x.dim() != 4 or x.shape[3] not in (3, 4):
+        raise AdainHipError(f"resize_pil_bilinear_u8: expected uint8 [n,h,w,3|4], got {tuple(x.shape)}")
+    n, hi, wi, pix = x.shape
+    wo, ho = int(size[0]), int(size[1])
+    y0, x0, ch, cw = (0, 0, ho, wo) if crop is None else [int(v) for v in crop]
+    if out is None:
+        out = torch.empty((n, max(ch, 0), max(cw, 0), 3), dtype=torch.uint8, device=x.device)
+    elif tuple(out.shape) != (n, ch, cw, 3) or out.dtype != torch.uint8 or not out.is_contiguous() or out.device != x.device:
+        raise AdainHipError(f"resize_pil_bilinear_u8: out must be a contiguous uint8 [{n},{ch},{cw},3] on {x.device}")
+    ws = workspace(x.device, "pil", lib().adain_resize_pil_bilinear_u8_workspace_bytes(hi, wi, ho, wo))
+    with torch.cuda.device(x.device):
+        _check(lib().adain_resize_pil_bilinear_u8(x.data_ptr(), pix, n, hi, wi, out.data_ptr(), ho, wo, y0, x0, ch, cw, ws.data_ptr(), ws.numel(),
+                                                  _stream()), "adain_resize_pil_bilinear_u8")
+    return out
 
 
 def nhwc_to_nchw(x):

@@ -160,6 +160,18 @@ ADAIN_API int adain_warp_blend_u8(const uint8_t* cur_u8, const uint8_t* prev_u8,
 ADAIN_API int adain_resize_area_u8(const uint8_t* in_u8, uint8_t* out_u8, int n, int hi, int wi, int c, int ho, int wo,
                          adain_stream_t stream);
 
+/* ---- test_transform's Resize [+ CenterCrop] on the device (test.py:16-24, applied at :190-204; video/utils.py:341-350) --------
+ * PIL.Image.resize((wo, ho), BILINEAR) of uint8 RGB images, bit for bit (Pillow's ImagingResample: separable triangle filter whose
+ * support grows with the shrink factor, double-precision taps converted to 22-bit fixed point, a horizontal pass into a uint8
+ * intermediate, then a vertical pass, clip8) - what torchvision's Resize(size) runs on a PIL image.  in: [n][hi][wi][pixel_bytes]
+ * with pixel_bytes = 3 (packed RGB) or 4 (Pillow's RGBX storage, 4th byte ignored); out: packed RGB [n][crop_h][crop_w][3] = the
+ * window (crop_y0, crop_x0, crop_h, crop_w) of the ho x wo result (CenterCrop(size): top = round((ho - size) / 2), left likewise;
+ * no crop: 0, 0, ho, wo).  The result feeds adain_encode_u8 / adain_stylize_u8 directly.  Workspace: the tap tables of both axes. */
+ADAIN_API size_t adain_resize_pil_bilinear_u8_workspace_bytes(int hi, int wi, int ho, int wo);
+ADAIN_API int adain_resize_pil_bilinear_u8(const uint8_t* in_u8, int pixel_bytes, int n, int hi, int wi, uint8_t* out_rgb_u8, int ho, int wo,
+                                 int crop_y0, int crop_x0, int crop_h, int crop_w, void* workspace, size_t workspace_bytes,
+                                 adain_stream_t stream);
+
 /* ---- one sub-batch of the reference's batch callers in ONE call ---------------------------------------------------------------
  * What adain_inference does between `Image.open` and `save_image` for n decoded frames of one size and one style whose
  * statistics are already known (test.py:203-244 per frame; the callers loop over frames with the same style,
