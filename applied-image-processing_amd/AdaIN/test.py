@@ -99,6 +99,63 @@ def test_transform_u8(size, crop):
 test_transform_u8.__test__ = False
 
 
+# ---- test_transform on the device (round 5): the decoded RGB bytes go up as they are, Resize [+ CenterCrop] run as ONE kernel that
+# reproduces PIL.Image.resize(BILINEAR) bit for bit (csrc/resample.hip, adain_resize_pil_bilinear_u8), ToTensor happens inside the
+# encoder's first layer.  What stays on the host: opening / decoding the file (PIL) and the copy of its pixels into a pinned buffer.
+_staging = threading.local()      # per thread (the job feeders fetch frames on a pool): {device index: [pinned uint8 buffer, event after its last upload]}
+
+
+def _upload_rgb(img, device):
+    """The pixels of an RGB PIL image as a uint8 [1,h,w,3] device tensor: ``tobytes`` into this thread's pinned staging buffer
+    (grown on demand, reused once its previous upload has finished), one asynchronous copy on the current stream."""
+    w, h = img.size
+    raw = img.tobytes()
+    n = len(raw)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    slots = _staging.__dict__.setdefault("slots", {})
+    slot = slots.get(idx)
+    if slot is None or slot[0].numel() < n:
+        slot = slots[idx] = [torch.empty(max(n, 1 << 22), dtype=torch.uint8).pin_memory(), None]
+    if slot[1] is not None:
+        slot[1].synchronize()
+    slot[0].numpy()[:n] = np.frombuffer(raw, dtype=np.uint8)
+    with torch.cuda.device(device):
+        x = torch.empty((1, h, w, 3), dtype=torch.uint8, device=device)
+        x.view(-1).copy_(slot[0][:n], non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+    return x
+
+
+def _transform_window(w, h, size, crop):
+    """((new width, new height), crop window | None) of ``test_transform(size, crop)`` for a w x h image; None when torchvision's
+    CenterCrop would have to pad (an image smaller than the crop: the host path handles it)."""
+    nw, nh = _resize_size(w, h, size) if size != 0 else (w, h)
+    if not crop:
+        return (nw, nh), None
+    if nw < size or nh < size:
+        return None
+    return (nw, nh), (int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0)), size, size)
+
+
+def device_transform_u8(img, size, crop, device):
+    """``test_transform_u8(size, crop)(img)`` for an RGB PIL image, computed on the device: uint8 [1,h,w,3], byte for byte what PIL's
+    resize + crop give (tests/test_gpu_resize_pil.py).  None for anything else (RGBA, L, ...: Pillow resizes those through other
+    paths - premultiplied alpha for RGBA -, they keep the host transform)."""
+    if getattr(img, "mode", None) != "RGB":
+        return None
+    plan = _transform_window(img.size[0], img.size[1], size, crop)
+    if plan is None:
+        return None
+    (nw, nh), win = plan
+    x = _upload_rgb(img, device)
+    if (nw, nh) == img.size:                    # Image.resize to the size it has is a copy
+        if win is None:
+            return x
+        return x[:, win[0]:win[0] + win[2], win[1]:win[1] + win[3]].contiguous()
+    return rt.resize_pil_bilinear_u8(x, (nw, nh), crop=win)
+
+
 def save_image(tensor, path):
     """torchvision.utils.save_image for one image (test.py:243-244): x*255 + 0.5, clamp, uint8, PIL save.
     The quantisation runs on the GPU (adain_quantize_u8)."""
@@ -262,6 +319,9 @@ def get_style_embeddings(
 
     def make():
         STYLE_ENCODES[0] += 1
+        u8 = device_transform_u8(style_img, style_size, crop, device) if isinstance(enc, net.HipVGG) else None
+        if u8 is not None:                       # RGB: resized on the device, ToTensor inside the first layer (bit-identical)
+            return rt.encode_u8(u8, enc.packed(device)).permute(0, 3, 1, 2)
         return enc(_as_batch(style_img, style_size, crop, device, rgb_only=True))
 
     return _cached_style(style_img, "features", style_size, crop, enc, device, make).clone()
@@ -388,9 +448,19 @@ def adain_inference(
     pil_content = Image.open(content_img) if type(content_img) == str else content_img
     if _style_cache_on and not preserve_color and isinstance(enc, net.HipVGG) and isinstance(dec, net.HipDecoder):
         # one style, many calls (video/utils.py:341-350, train.py:101): statistics from the cache, the frame in one C-ABI call
-        frame = test_transform_u8(content_size, crop)(pil_content)
-        T("open + resize content", t0)
-        if isinstance(frame, np.ndarray) and _mask_fits(content_mask):
+        pil_content.load()                                               # decode (a lazily opened file) - host work that stays
+        T("open + decode content (PIL)", t0)
+        t0 = time.perf_counter()
+        if T.on:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        frame = device_transform_u8(pil_content, content_size, crop, device)     # upload + Resize [+ CenterCrop] on the device
+        if frame is None:
+            frame = test_transform_u8(content_size, crop)(pil_content)           # not RGB / padded crop: PIL on the host
+            T("resize content (PIL, host)", t0)
+        else:
+            T("upload + resize content (device; enqueue only)", t0)
+        if (isinstance(frame, np.ndarray) or isinstance(frame, torch.Tensor) and frame.dtype == torch.uint8) and _mask_fits(content_mask):
             assert 0.0 <= alpha <= 1.0                                   # test.py:55 / :75
             if use_depth:
                 assert 0.0 <= depth_offset <= 1.0                        # test.py:56
@@ -399,10 +469,13 @@ def adain_inference(
             T("style statistics (cached after the first call)", t0)
             if stats is not None:
                 _one_call(frame, stats, enc, dec, device, alpha, use_depth, depth_map, pil_content, depth_offset, depth_prominence, content_mask,
-                          target)
+                          target, e0 if T.on else None)
                 print(f"Image saved to {target}")
                 return target
-        content = _to_tensor(Image.fromarray(frame)) if isinstance(frame, np.ndarray) else frame
+        if isinstance(frame, torch.Tensor) and frame.dtype == torch.uint8:
+            content = frame[0].cpu().permute(2, 0, 1).float().div(255)      # ToTensor of the resized frame (same bytes as PIL's)
+        else:
+            content = _to_tensor(Image.fromarray(frame)) if isinstance(frame, np.ndarray) else frame
     else:
         content = test_transform(content_size, crop)(pil_content)
     pil_style = Image.open(str(style_img)) if type(style_img) == str else style_img
@@ -466,6 +539,10 @@ def _style_stats(style_img, style_size, crop, enc, device, drop_alpha):
     alpha blend: the reference fails in its first convolution; the call-by-call path reports it)."""
     def make():
         pil_style = Image.open(str(style_img)) if type(style_img) == str or isinstance(style_img, Path) else style_img
+        u8 = device_transform_u8(pil_style, style_size, crop, device)
+        if u8 is not None:                                                # RGB: Resize on the device, ToTensor inside the first layer
+            STYLE_ENCODES[0] += 1
+            return rt.mean_std(rt.encode_u8(u8, enc.packed(device)), True)
         style = test_transform(style_size, crop)(pil_style)
         if style.shape[0] == 4 and drop_alpha:
             style = style[:3]                                             # test.py:60-61
@@ -479,8 +556,10 @@ def _style_stats(style_img, style_size, crop, enc, device, drop_alpha):
     return _cached_style(style_img, ("stats", bool(drop_alpha)), style_size, crop, enc, device, make)
 
 
-def _one_call(frame, stats, enc, dec, device, alpha, use_depth, depth_map, pil_content, depth_offset, depth_prominence, content_mask, target):
-    """A resized RGB frame (uint8 HWC, host) -> the saved file: upload, ``adain_stylize_u8``, download, PIL save."""
+def _one_call(frame, stats, enc, dec, device, alpha, use_depth, depth_map, pil_content, depth_offset, depth_prominence, content_mask, target,
+              e0=None):
+    """A resized RGB frame (uint8: [1,h,w,3] on the device, or HWC on the host) -> the saved file: [upload,] ``adain_stylize_u8``,
+    download, PIL save.  ``e0``: an event recorded before the device-side resize (stage timer: the kernels' time includes it)."""
     T = _stage_timer
     depth = None
     if use_depth:
@@ -490,18 +569,23 @@ def _one_call(frame, stats, enc, dec, device, alpha, use_depth, depth_map, pil_c
             proximity = torch.as_tensor(np.asarray(proximity))
         T("depth provider", t0)
     t0 = time.perf_counter()
-    x = torch.from_numpy(frame if frame.flags.writeable else frame.copy()).unsqueeze(0).to(device)     # (np.asarray of a PIL image is read-only)
+    if isinstance(frame, torch.Tensor):
+        x = frame
+    else:
+        x = torch.from_numpy(frame if frame.flags.writeable else frame.copy()).unsqueeze(0).to(device)     # (np.asarray of a PIL image is read-only)
     if use_depth:
         depth = [proximity.to(device=device, dtype=torch.float32).contiguous()]
     mask = None
     if content_mask is not None:
         m = content_mask if isinstance(content_mask, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(content_mask))
         mask = m.to(device).unsqueeze(0)                                 # test.py:224-226 (the .float() happens in the kernel)
-    T("upload (frame, depth map, mask)", t0)
+    T("upload (depth map, mask)", t0)
     t0 = time.perf_counter()
     if T.on:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e1 = torch.cuda.Event(enable_timing=True)
+        if e0 is None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
     u8 = rt.stylize_u8(x, enc.packed(device), dec.packed(device), stats[0], stats[1], alpha, depth, depth_offset, depth_prominence, mask)
     if T.on:
         e1.record()

@@ -88,9 +88,11 @@ __device__ __forceinline__ void buf_store4(rsrc_t r, f32x4 v, int voff) {
 // OIHW [cout][cin][3][3] -> U = G4 g G2^T packed as [cout/32][j 4][cin/8][r 6][lane 64][s 4]:
 //   value = U[r][j][cout = 32 ct + (lane & 31)][cin = 8 chunk + 4 (lane >> 5) + s]
 __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict__ p, int cin, int cout) {
-    const float G2[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-    const float G4[6][3] = {{0.25f, 0.f, 0.f},           {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
-                            {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    // transformed in double and rounded once: U carries half an ulp instead of the few ulp of nine fp32 products with 1/6, 1/12, 1/24
+    // (a systematic, per-weight error; runs once per weight set)
+    const double G2[4][3] = {{1., 0., 0.}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0., 0., 1.}};
+    const double G4[6][3] = {{0.25, 0., 0.},           {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
+                             {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
     const size_t total = (size_t)cin * cout * 24;
     const int nch = cin / 8;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -103,12 +105,12 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
         const int ct = (int)t;
         const int co = ct * 32 + (lane & 31), ci = chunk * 8 + 4 * (lane >> 5) + s;
         const float* g = w + ((size_t)co * cin + ci) * 9;
-        float u = 0.f;
+        double u = 0.;
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) u += G4[r][a] * g[a * 3 + b] * G2[j][b];
-        p[idx] = u;
+            for (int b = 0; b < 3; ++b) u += G4[r][a] * (double)g[a * 3 + b] * G2[j][b];
+        p[idx] = (float)u;
     }
 }
 

@@ -840,7 +840,7 @@ def precompute_guides_sharded(engine, views, names, output_dir, style, *, masks=
     behind them.  Every rank returns the full {name: Path} map once all files exist (an error on any rank raises on all)."""
     from PIL import Image
 
-    from .AdaIN.test import test_transform_u8
+    from .AdaIN.test import device_transform_u8, test_transform_u8
 
     if write not in ("dst", "local"):
         raise ValueError("write must be 'dst' or 'local'")
@@ -857,8 +857,15 @@ def precompute_guides_sharded(engine, views, names, output_dir, style, *, masks=
             v = views[k]
             if isinstance(v, (str, Path)):
                 v = Image.open(str(v))
-            return v if isinstance(v, (torch.Tensor, np.ndarray)) else tf(v)
+            if isinstance(v, (torch.Tensor, np.ndarray)):
+                return v
+            if on_gpu:                    # RGB: the decoded bytes go up, Resize [+ CenterCrop] run on the device (PIL's bytes exactly)
+                d = device_transform_u8(v, content_size, crop, engine.device)
+                if d is not None:
+                    return d[0]
+            return tf(v)
 
+    on_gpu = torch.device(engine.device).type == "cuda"
     names = list(names)
     paths = {nm: out_dir / f"{nm}{save_ext}" for nm in names}
     sink = FileSink(engine.device, workers=writers)

@@ -524,6 +524,9 @@ def resize_area_u8(frames, dsize):
     return out[0] if single else out
 
 
+_pil_lock = threading.Lock()
+
+
 def resize_pil_bilinear_u8(frames, size, crop=None, out=None):
     """``PIL.Image.resize(size, BILINEAR)`` of uint8 images on the device, bit for bit (test.py:16-24's Resize on a PIL image).
     frames: uint8 [n,h,w,3] (packed RGB) or [n,h,w,4] (Pillow's RGBX storage); ``size`` = (width, height) as PIL takes it;
@@ -538,8 +541,10 @@ def resize_pil_bilinear_u8(frames, size, crop=None, out=None):
         out = torch.empty((n, max(ch, 0), max(cw, 0), 3), dtype=torch.uint8, device=x.device)
     elif tuple(out.shape) != (n, ch, cw, 3) or out.dtype != torch.uint8 or not out.is_contiguous() or out.device != x.device:
         raise AdainHipError(f"resize_pil_bilinear_u8: out must be a contiguous uint8 [{n},{ch},{cw},3] on {x.device}")
-    ws = workspace(x.device, "pil", lib().adain_resize_pil_bilinear_u8_workspace_bytes(hi, wi, ho, wo))
-    with torch.cuda.device(x.device):
+    # the tap tables live in the stream's workspace between the call's two launches: calls from several threads (the job feeders'
+    # fetch pool) on one stream must not interleave
+    with _pil_lock, torch.cuda.device(x.device):
+        ws = workspace(x.device, "pil", lib().adain_resize_pil_bilinear_u8_workspace_bytes(hi, wi, ho, wo))
         _check(lib().adain_resize_pil_bilinear_u8(x.data_ptr(), pix, n, hi, wi, out.data_ptr(), ho, wo, y0, x0, ch, cw, ws.data_ptr(), ws.numel(),
                                                   _stream()), "adain_resize_pil_bilinear_u8")
     return out

@@ -100,6 +100,7 @@ def _run(content_dir, style_paths, output_dir, flow_method, alpha, target_resolu
     if engine is None:
         engine = AdaINEngine(torch.load(vgg_str, map_location="cpu"), torch.load(decoder_str, map_location="cpu"))
     tf = adain_test.test_transform_u8(256, False)              # adain_inference(content_size=256) of the reference loop
+    on_gpu = torch.device(engine.device).type == "cuda"
     stf = adain_test.test_transform(512, False)                # its default style_size
 
     class Frames:                                             # lazily: a rank opens only the frames of its own block
@@ -107,7 +108,10 @@ def _run(content_dir, style_paths, output_dir, flow_method, alpha, target_resolu
             return len(names)
 
         def __getitem__(self, k):
-            return tf(Image.open(os.path.join(content_dir, names[k])).convert("RGB"))
+            img = Image.open(os.path.join(content_dir, names[k])).convert("RGB")
+            if on_gpu:                                        # Resize(256) on the device, PIL's bytes exactly (csrc/resample.hip)
+                return adain_test.device_transform_u8(img, 256, False, engine.device)[0]
+            return tf(img)
 
     class Depths:
         def __len__(self):

@@ -144,6 +144,51 @@ def resize_size(h, w, size):
     return (new_long, new_short) if w <= h else (new_short, new_long)
 
 
+def pil_resample_taps(in_size, out_size):
+    """Pillow libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR (triangle, support 1) filter over
+    the whole axis (box = (0, in_size)): per output index (first source index, fixed-point taps).  Pillow is a third-party
+    dependency of the reference (requirements.txt:1, unpinned; torchvision 0.13.1's Resize on a PIL image calls
+    ``Image.resize(size, BILINEAR)``, test.py:16-24); PINNED: tests/test_oracle_golden.py checks this restatement against the
+    Pillow installed in the image (12.2.0) on the callers' size pairs and random ones, byte for byte."""
+    import numpy as np
+
+    scale = float(np.float32(in_size) - np.float32(0.0)) / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ss = 1.0 / filterscale
+    taps = []
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        t = [abs(((x + xmin) - center + 0.5) * ss) for x in range(xmax)]
+        w = [1.0 - v if v < 1.0 else 0.0 for v in t]        # bilinear_filter
+        ww = sum(w, 0.0)                                     # left-to-right double additions, as the C loop does
+        if ww != 0.0:
+            w = [v / ww for v in w]
+        taps.append((xmin, np.array([int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22)) for v in w], dtype=np.int64)))
+    return taps
+
+
+def resize_pil_bilinear_u8(img, size):
+    """``PIL.Image.resize(size, BILINEAR)`` of a uint8 [H,W,C] array, restated (Resample.c ImagingResample, 8 bits per channel):
+    horizontal pass into a uint8 intermediate, vertical pass, each ``clip8((2^21 + sum in * k) >> 22)``.  ``size`` = (width,
+    height).  See ``pil_resample_taps`` for the pin."""
+    import numpy as np
+
+    def one_axis(a, taps):                                    # resamples axis 1 of [R, S, C]
+        out = np.empty((a.shape[0], len(taps), a.shape[2]), dtype=np.uint8)
+        src = a.astype(np.int64)
+        for xx, (xmin, k) in enumerate(taps):
+            acc = (1 << 21) + (src[:, xmin:xmin + len(k), :] * k[None, :, None]).sum(axis=1)
+            out[:, xx, :] = np.clip(acc >> 22, 0, 255)
+        return out
+
+    wo, ho = size
+    tmp = one_axis(img, pil_resample_taps(img.shape[1], wo))
+    return one_axis(tmp.transpose(1, 0, 2), pil_resample_taps(img.shape[0], ho)).transpose(1, 0, 2)
+
+
 def psnr(a, b):
     """Style_3DGS/utils/image_utils.py:17-19 — 20*log10(1/sqrt(mse)) per image on [0,1] data."""
     mse = ((a - b) ** 2).reshape(a.shape[0], -1).mean(1)

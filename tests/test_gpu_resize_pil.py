@@ -99,3 +99,42 @@ def test_a_large_photograph_sized_frame(rt):
     a = picture(9, 2160, 3840)                                                     # a 4K frame to the guide loop's 512: 15-tap rows
     got = rt.resize_pil_bilinear_u8(torch.from_numpy(a[None]).cuda(), (910, 512))[0].cpu().numpy()
     assert np.array_equal(got, pil_resize(a, (910, 512)))
+
+
+def test_device_transform_is_test_transform_u8(rt):
+    """``device_transform_u8`` (upload + Resize [+ CenterCrop] on the device) against ``test_transform_u8`` (PIL on the host, the
+    restatement of test.py:16-24): the same bytes for every (size, crop) the callers use; images Pillow resizes through other code
+    (RGBA: premultiplied alpha; L) and crops torchvision would pad stay on the host path."""
+    from applied_image_processing_amd.AdaIN import test as t
+
+    dev = torch.device("cuda:0")
+    for (h, w) in [(270, 480), (700, 933), (800, 800), (96, 64)]:
+        img = Image.fromarray(picture(400 + h, h, w))
+        for size, crop in [(256, False), (256, True), (512, False), (0, False), (64, True), (h if h < w else w, False)]:
+            want = t.test_transform_u8(size, crop)(img)
+            got = t.device_transform_u8(img, size, crop, dev)
+            if crop and min(want.shape[:2]) < size:
+                continue
+            assert got is not None and got.dtype == torch.uint8 and tuple(got.shape) == (1,) + want.shape, (h, w, size, crop)
+            assert np.array_equal(got[0].cpu().numpy(), want), (h, w, size, crop)
+    small = Image.fromarray(picture(7, 40, 60))
+    assert t.device_transform_u8(small, 0, True, dev) is None or True           # (size 0 with crop never occurs: CenterCrop(0))
+    assert t.device_transform_u8(small.convert("RGBA"), 32, False, dev) is None
+    assert t.device_transform_u8(small.convert("L"), 32, False, dev) is None
+
+
+def test_device_transform_from_several_threads(rt):
+    """The job feeders fetch (decode + transform) frames on a thread pool: per-thread staging buffers, one lock around a resize's two
+    launches - concurrent calls with different sizes must each give PIL's bytes."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from applied_image_processing_amd.AdaIN import test as t
+
+    dev = torch.device("cuda:0")
+    imgs = [Image.fromarray(picture(500 + k, 100 + 7 * k, 140 + 11 * (k % 5))) for k in range(24)]
+    want = [t.test_transform_u8(64 + (k % 3) * 8, False)(im) for k, im in enumerate(imgs)]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        got = list(ex.map(lambda kv: t.device_transform_u8(kv[1], 64 + (kv[0] % 3) * 8, False, dev), enumerate(imgs)))
+    torch.cuda.synchronize()
+    for k in range(len(imgs)):
+        assert np.array_equal(got[k][0].cpu().numpy(), want[k]), k

@@ -314,3 +314,20 @@ def test_case_g_trained_like_weights(weights_tl):
         for key in ("relu1_1", "content_f", "adain", "out_a05", "out_a10", "out_depth"):
             floor = rel_l2(g[f"{tag}_{key}"], g[f"{tag}_{key}_f64"])
             assert floor < (2e-7 if key == "relu1_1" else 1e-5 if key in ("content_f", "adain") else 6e-5), (tag, key, floor)
+
+
+# ---- row a9: test_transform's Resize = PIL.Image.resize(BILINEAR); the restatement is pinned to the installed Pillow --------------
+def test_pil_bilinear_restatement_is_pillows_bytes():
+    """``O.resize_pil_bilinear_u8`` (Resample.c restated) against the Pillow the reference would call, byte for byte: the callers'
+    own size pairs and seeded random ones, shrinking and enlarging."""
+    from PIL import Image
+
+    g = np.random.default_rng(7)
+    pairs = [((70, 93), (34, 25)), ((27, 48), (45, 25)), ((80, 80), (51, 51)), ((16, 12), (50, 31)), ((31, 57), (31, 20)), ((108, 192), (45, 25))]
+    pairs += [((int(g.integers(1, 90)), int(g.integers(1, 90))), (int(g.integers(1, 120)), int(g.integers(1, 120)))) for _ in range(40)]
+    for (h, w), size in pairs:
+        a = (synth.image(500 + h + w, 1, h, w)[0].transpose(1, 2, 0) * np.float32(255)).astype(np.uint8)
+        a[a > 230] = 255
+        a[a < 25] = 0
+        want = np.asarray(Image.fromarray(a).resize(size, Image.BILINEAR))
+        assert np.array_equal(O.resize_pil_bilinear_u8(a, size), want), ((h, w), size)
