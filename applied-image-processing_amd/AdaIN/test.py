@@ -105,7 +105,7 @@ test_transform_u8.__test__ = False
 _staging = threading.local()      # per thread (the job feeders fetch frames on a pool): {device index: [pinned uint8 buffer, event after its last upload]}
 
 
-def _upload_rgb(img, device):
+def _upload_rgb(img, device, mark=None):
     """The pixels of an RGB PIL image as a uint8 [1,h,w,3] device tensor: ``tobytes`` into this thread's pinned staging buffer
     (grown on demand, reused once its previous upload has finished), one asynchronous copy on the current stream."""
     w, h = img.size
@@ -121,6 +121,8 @@ def _upload_rgb(img, device):
     slot[0].numpy()[:n] = np.frombuffer(raw, dtype=np.uint8)
     with torch.cuda.device(device):
         x = torch.empty((1, h, w, 3), dtype=torch.uint8, device=device)
+        if mark is not None:
+            mark()                              # (stage timer: the device work of a call starts here)
         x.view(-1).copy_(slot[0][:n], non_blocking=True)
         slot[1] = torch.cuda.Event()
         slot[1].record()
@@ -138,7 +140,7 @@ def _transform_window(w, h, size, crop):
     return (nw, nh), (int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0)), size, size)
 
 
-def device_transform_u8(img, size, crop, device):
+def device_transform_u8(img, size, crop, device, mark=None):
     """``test_transform_u8(size, crop)(img)`` for an RGB PIL image, computed on the device: uint8 [1,h,w,3], byte for byte what PIL's
     resize + crop give (tests/test_gpu_resize_pil.py).  None for anything else (RGBA, L, ...: Pillow resizes those through other
     paths - premultiplied alpha for RGBA -, they keep the host transform)."""
@@ -148,7 +150,7 @@ def device_transform_u8(img, size, crop, device):
     if plan is None:
         return None
     (nw, nh), win = plan
-    x = _upload_rgb(img, device)
+    x = _upload_rgb(img, device, mark)
     if (nw, nh) == img.size:                    # Image.resize to the size it has is a copy
         if win is None:
             return x
@@ -451,10 +453,8 @@ def adain_inference(
         pil_content.load()                                               # decode (a lazily opened file) - host work that stays
         T("open + decode content (PIL)", t0)
         t0 = time.perf_counter()
-        if T.on:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-        frame = device_transform_u8(pil_content, content_size, crop, device)     # upload + Resize [+ CenterCrop] on the device
+        e0 = torch.cuda.Event(enable_timing=True) if T.on else None
+        frame = device_transform_u8(pil_content, content_size, crop, device, e0.record if T.on else None)     # upload + Resize [+ CenterCrop] on the device
         if frame is None:
             frame = test_transform_u8(content_size, crop)(pil_content)           # not RGB / padded crop: PIL on the host
             T("resize content (PIL, host)", t0)
@@ -469,7 +469,7 @@ def adain_inference(
             T("style statistics (cached after the first call)", t0)
             if stats is not None:
                 _one_call(frame, stats, enc, dec, device, alpha, use_depth, depth_map, pil_content, depth_offset, depth_prominence, content_mask,
-                          target, e0 if T.on else None)
+                          target, e0 if (T.on and isinstance(frame, torch.Tensor)) else None)
                 print(f"Image saved to {target}")
                 return target
         if isinstance(frame, torch.Tensor) and frame.dtype == torch.uint8:

@@ -970,7 +970,7 @@ def main_per_call(args, ctx):
                                       "one 933x700 style file resized to 512 (video/utils.py:341-350)" if mode == "video" else
                                       f"{n} calls: {h}x{w} PIL views, content_size=512 -> {ch}x{cw}, mask = view > 0, one 933x700 PIL style resized to 512 "
                                       "(Style_3DGS/train.py:86-115)") + ", fp32, seeded synthetic weights", "parallelism": "single GPU, one call at a time"},
-              "per_call": {"ms": round(dt * 1e3 / n, 3), "stages_ms": stages, "kernels_ms_by_hip_events": round(gpu_ms, 3),
+              "per_call": {"ms": round(dt * 1e3 / n, 3), "stages_ms": stages, "kernels_ms_by_hip_events": round(gpu_ms, 3),     # from the frame's H2D copy to the last kernel (upload, resize, ~27 launches)
                            "outside_the_stages_ms": round(dt * 1e3 / n - sum(stages.values()), 3),      # the caller's own work (PIL object / mask
                                                                                                        # construction in the loop) + bookkeeping
                            "calling_thread_cpu_ms": round(cpu * 1e3 / n, 3), "process_cpu_ms": round(pcpu * 1e3 / n, 3),

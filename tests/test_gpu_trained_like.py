@@ -139,3 +139,24 @@ def test_larger_frames_against_the_oracle_and_float64(rt, weights_tl, h, w, hs, 
     d = (u8.int() - O.quantize_u8(ref).int()).abs()
     assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 2e-2          # measured: 0.8 % of the bytes one LSB off
     assert torch.equal(u8, eng.to_u8(eng.stylize(T(cu8[None]).cuda(), 0.5)).cpu())
+
+
+def test_real_checkpoint_acceptance_script_runs_end_to_end(rt, weights_tl, tmp_path, capsys):
+    """tests/verify_real_weights.py, compute part: checkpoints in the reference's key layout (the trained-like set standing in for
+    the files nobody here has), the reference's sample pair at 256 from tests/golden/case_f.npz; passes at this regime's stated
+    tolerance, fails (non-zero, the stage named) at an impossible one."""
+    import verify_real_weights as v
+
+    torch.save(weights_tl[0], tmp_path / "vgg.pth")
+    torch.save(weights_tl[1], tmp_path / "dec.pth")
+    base = ["--vgg", str(tmp_path / "vgg.pth"), "--decoder", str(tmp_path / "dec.pth"), "--content", "", "--style", "", "--any-weights", "--sizes", "256", "512"]
+    rc = v.main(base + ["--tol", str(TOL)])
+    rep = json.loads(capsys.readouterr().out)
+    assert rc == 0 and rep["verdict"] == "PASS", rep["problems"]
+    st = rep["runs"]["256"]["stages"]
+    assert st["uint8 image"]["max_abs_lsb"] <= 1 and st["output"]["psnr_db"] > 60 and "skipped" in rep["runs"]["512"]
+    assert rep["weights"]["conv0_bias"] == [-103.939, -116.779, -123.68]
+    REPORT["real_image_pair_256"] = st
+    rc = v.main(base + ["--tol", "1e-9"])
+    rep = json.loads(capsys.readouterr().out)
+    assert rc == 1 and rep["verdict"] == "FAIL" and any("relu4_1(content)" in p for p in rep["problems"])

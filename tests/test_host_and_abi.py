@@ -275,3 +275,33 @@ def test_headers_are_plain_c_and_cxx(tmp_path, header):
     for cmd in (["gcc", "-std=c99", "-pedantic-errors", "-Wall", "-Werror", "-fsyntax-only"], ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++"]):
         r = subprocess.run(cmd + ["-I", inc, str(src)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_real_checkpoint_acceptance_script_checks_files_and_layout(tmp_path, capsys):
+    """tests/verify_real_weights.py on synthetic ``.pth`` files of the reference key layout: the layout passes, the files are
+    (correctly) reported as NOT the reference's checkpoints - size and sha256 differ from the LFS pointers - and a checkpoint with a
+    missing / misshapen tensor is named.  The compute part needs a GPU (test_gpu_configs.py runs it there)."""
+    import json
+
+    import verify_real_weights as v
+
+    vgg, dec = synth.to_torch(synth.vgg_state_dict(0, full=True)), synth.to_torch(synth.decoder_state_dict(0))
+    torch.save(vgg, tmp_path / "vgg.pth")
+    torch.save(dec, tmp_path / "dec.pth")
+    assert v.check_layout(vgg, "vgg") == [] and v.check_layout(dec, "decoder") == []
+    f = v.check_file(tmp_path / "vgg.pth", "vgg")
+    assert not f["ok"] and not f["size_matches"] and f["sha256_matches"] is False and len(f["sha256"]) == 64
+    assert v.POINTERS["vgg"]["size"] == 80102481 and v.POINTERS["decoder"]["size"] == 14023458       # the reference's LFS pointers
+    rc = v.main(["--vgg", str(tmp_path / "vgg.pth"), "--decoder", str(tmp_path / "dec.pth"), "--files-only"])
+    rep = json.loads(capsys.readouterr().out)
+    assert rc == 1 and rep["verdict"] == "FAIL" and len(rep["problems"]) == 2 and all("not the reference's" in p for p in rep["problems"])
+    rc = v.main(["--vgg", str(tmp_path / "vgg.pth"), "--decoder", str(tmp_path / "dec.pth"), "--files-only", "--any-weights"])
+    rep = json.loads(capsys.readouterr().out)
+    assert rc == 0 and rep["verdict"] == "PASS" and rep["weights"]["conv0_weight"][0] != 0
+    broken = dict(dec)
+    del broken["28.bias"]
+    broken["1.weight"] = broken["1.weight"][:, :100]
+    torch.save(broken, tmp_path / "bad.pth")
+    rc = v.main(["--vgg", str(tmp_path / "vgg.pth"), "--decoder", str(tmp_path / "bad.pth"), "--files-only", "--any-weights"])
+    rep = json.loads(capsys.readouterr().out)
+    assert rc == 1 and any("missing key 28.bias" in p for p in rep["problems"]) and any("1.weight: shape" in p for p in rep["problems"])
