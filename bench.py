@@ -1051,10 +1051,19 @@ def main():
         last[0] = step.run(to_u8=use_dist, u8_out=slot if need_u8 else None)
 
     last = [None]
+    phases, t_phase = {}, [time.perf_counter()]
+
+    def phase(name):          # wall seconds of this process since the previous mark (the line says where the run's time went)
+        now = time.perf_counter()
+        phases[name] = round(phases.get(name, 0.0) + now - t_phase[0], 3)
+        t_phase[0] = now
+
     ctx.warm_transport(n_job, args.batch)
+    phase("setup (weights, inputs, packing, transport)")
     dt, gathered, tinfo = jobs.run_timed_steps(one_step, args.steps, args.warmup, barrier=barrier, block_shape=(args.batch, oh, ow, 3),
                                                device=device, mode=args.gather, gather=use_dist, mark=step.engine.mark,
                                                elapsed=step.engine.elapsed)
+    phase("warm-up + timed steps")
     out = last[0]
     per_rank = [None] * world
     mine = {"rank": rank, "compute_ms": round(tinfo["compute_ms"], 3), "gather_ms": round(tinfo["gather_ms"], 3),
@@ -1092,10 +1101,12 @@ def main():
         sustained = {"seconds": round(sdt, 3), "steps": k_s, "value": round(n_job * h * w / 1e6 / (sdt / k_s), 3),
                      "ms_per_step": round(sdt / k_s * 1e3, 4), "unit": "Mpixels/s"}
 
+    phase("isolated gather + sustained leg")
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = n_job * h * w / 1e6 / (dt / args.steps)
         roof, layers, secondary = measure_roofline(step, 5)
+        phase("roofline leg (instrumented steps)")
         result = base_result(args, ctx, value, ms, WORKLOADS[args.config].format(h=h, w=w, hs=hs, ws=ws, b=args.batch, alpha=args.alpha)
                              + ("; depth-aware variant (a proximity map per frame, offset 0.30, prominence 20)" if args.depth else ""),
                              f"frame sharding x{world}: contiguous frame blocks per rank, replicated weights and style statistics, "
@@ -1134,10 +1145,12 @@ def main():
                                         "ms_per_step": round(pdt * 1e3, 4), "what": "pinned fp32 frame H2D + forward + uint8 D2H per step"}
         if not args.no_secondary:              # rank 0's GPU, after the timed region (the other ranks wait in the final rendezvous)
             result["secondary"] += measure_pixel_kernels(device)
+        phase("pcie / secondary pixel kernels")
         if not args.no_cpu:                    # rank 0's host cores, after the timed region, at every N (north_star: "in the same run")
             out = step.run()
             torch.cuda.synchronize()
             cb, psnr, rel = cpu_baseline(step, step.u8 if args.config in (4, 5) else out)
+            phase("cpu_baseline (the GPU idles)")
             if world > 1:
                 cb["sample"] += f"; measured on rank 0 after the timed region while the other {world - 1} rank(s) wait in the final host rendezvous"
             result["cpu_baseline"] = cb
@@ -1146,6 +1159,9 @@ def main():
         if args.layers and layers:
             for i, L in enumerate(layers):
                 print(f"layer {i:2d}: {L['gflop']:8.2f} GF  {L['ms']:8.4f} ms  {L['tflops']:7.2f} TF/s", file=sys.stderr)
+        # where this process's wall time went: the K timed steps are a fraction of a second of a run dominated by set-up and the CPU
+        # baseline, so a utilisation sampler beside the whole run sees a mostly idle GPU
+        result["run_phases_s"] = phases
         emit(result)
     ctx.finish()
 
