@@ -220,7 +220,6 @@ def trained_like_state_dicts(seed=0):
         s = _round_bits(1.0 / np.maximum(mean, 0.25 * np.median(mean))).astype(np.float32)     # (rarely firing channels: gain capped)
         return w * s[:, None, None, None], b * s
 
-    nthreads = torch.get_num_threads()
     vgg = vgg_state_dict(seed, full=True)                   # the convs behind relu4_1 stay Kaiming: net.vgg[:31] never runs them
     vgg["0.weight"] = (np.float32(255.0) * np.eye(3, dtype=np.float32)[::-1]).reshape(3, 3, 1, 1).copy()
     vgg["0.bias"] = np.array([-103.939, -116.779, -123.68], dtype=np.float32)
@@ -252,7 +251,6 @@ def trained_like_state_dicts(seed=0):
                 w = w * s[:, None, None, None]
                 b = _round_bits(0.5 - s.astype(np.float64) * y.mean(dim=(0, 2, 3)).numpy()).astype(np.float32)
             dec[f"{i}.weight"], dec[f"{i}.bias"] = w, b
-    torch.set_num_threads(nthreads)
     _TL_CACHE[seed] = (vgg, dec)
     return vgg, dec
 
