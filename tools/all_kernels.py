@@ -83,8 +83,12 @@ for rep in range(3):
     odd_u8 = u8(19, 1, 45, 67)
     eng.stylize_u8(odd_u8, 0.5, masks=(odd_u8 > 40).permute(0, 3, 1, 2).contiguous())
     eng.stylize_u8(frames, depth_maps=[depth[:600, :800].contiguous(), depth], offset=0.3)     # depth-aware form
+    # test_transform's Resize on the device (Pillow-exact): packed RGB and Pillow's 4-byte storage, with a CenterCrop window
+    r3 = rt.resize_pil_bilinear_u8(u8(22, 1, 700, 933), (682, 512))                           # pil_coeffs_kernel + pil_resize_kernel<3>
+    r4 = rt.resize_pil_bilinear_u8(u8(23, 2, 270, 480, c=4), (455, 256), crop=(0, 100, 256, 256))    # pil_resize_kernel<4>
+    first = rt.encode_relu1_1(r3, eng.enc)                                                    # conv_first_kernel<true> alone
     torch.cuda.synchronize()
-called += ["adain_stylize_u8", "adain_encode_multi", "adain_encode_u8", "adain_encode", "adain_decode", "adain_mean_std", "adain_blend_alpha", "adain_blend_pmap",
+called += ["adain_resize_pil_bilinear_u8", "adain_encode_relu1_1", "adain_stylize_u8", "adain_encode_multi", "adain_encode_u8", "adain_encode", "adain_decode", "adain_mean_std", "adain_blend_alpha", "adain_blend_pmap",
            "adain_strength_map", "adain_u8_to_f32", "adain_resize_bilinear", "adain_resize_nearest", "adain_mask_composite", "adain_quantize_u8",
            "adain_resize_area_u8", "adain_warp_blend_u8", "adain_nhwc_to_nchw", "adain_nchw_to_nhwc"]
 # the single-layer entry point (BIG descriptors are exercised by tests/test_gpu_parity.py::test_conv_tensors_above_two_gib)
