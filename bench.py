@@ -50,6 +50,7 @@ import statistics
 import sys
 import time
 
+_T0 = time.perf_counter()          # this process's start, for `run_phases_s`
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
@@ -1035,7 +1036,14 @@ def main():
         return main_job(args, ctx)
     world, rank, device, use_dist, transport, shared_gpu = ctx.world, ctx.rank, ctx.device, ctx.use_dist, ctx.transport, ctx.shared_gpu
     barrier = ctx.barrier
+    phases, t_phase = {}, [_T0]
 
+    def phase(name):          # wall seconds of this process since the previous mark (the line says where the run's time went)
+        now = time.perf_counter()
+        phases[name] = round(phases.get(name, 0.0) + now - t_phase[0], 3)
+        t_phase[0] = now
+
+    phase("imports + process group")
     step = Step(device, config=args.config, first_frame=rank * args.batch, size=args.size, style_size=args.style_size, batch=args.batch, depth=args.depth,
                 alpha=args.alpha)
     h, w, hs, ws = step.h, step.w, step.hs, step.ws
@@ -1051,13 +1059,6 @@ def main():
         last[0] = step.run(to_u8=use_dist, u8_out=slot if need_u8 else None)
 
     last = [None]
-    phases, t_phase = {}, [time.perf_counter()]
-
-    def phase(name):          # wall seconds of this process since the previous mark (the line says where the run's time went)
-        now = time.perf_counter()
-        phases[name] = round(phases.get(name, 0.0) + now - t_phase[0], 3)
-        t_phase[0] = now
-
     ctx.warm_transport(n_job, args.batch)
     phase("setup (weights, inputs, packing, transport)")
     dt, gathered, tinfo = jobs.run_timed_steps(one_step, args.steps, args.warmup, barrier=barrier, block_shape=(args.batch, oh, ow, 3),
