@@ -580,7 +580,7 @@ def test_decoder_alone_vs_oracle(rt, weights, n, hc, wc):
 
 
 def test_random_shapes_vs_oracle(rt, nets, weights):
-    """Shape fuzz (a fixed seed; tools/fuzz_shapes.py runs more): random content / style sizes and batches - ragged tiles in
+    """Shape fuzz (a fixed seed; tests/fuzz_shapes.py runs more): random content / style sizes and batches - ragged tiles in
     both directions, several tiles across, tiny maps - through the alpha path, the depth path and the decoder alone."""
     from applied_image_processing_amd.AdaIN import test as t
 
