@@ -77,17 +77,30 @@ constexpr int CF_OSTR = 68;      // floats per pixel of the row buffer: b128 wri
 // U8: the image arrives as uint8 HWC [n][H][W][3] (a decoded frame as PIL / the job drivers hold it) and the kernel applies
 // torchvision's ToTensor itself, float(v) / 255 with a correctly rounded fp32 division (reference test.py:22, :203): the result is
 // bit-identical to encoding the float NCHW tensor, the frame crosses PCIe and HBM as 3 instead of 12 bytes per pixel.
+// Round 5 - a fifth of the vector instructions (~80 per wave and tile instead of ~500; every one costs the fp32 matrix pipe ~4 cycles
+// here).  Measured effect: none at 1024 x 1024 (74.6-74.9 against 75.0-76.0 us), -3 % on the uint8 entry at 1080p - the kernel is bound
+// neither by its vector instructions nor by its barriers or waits (tools/probes/notes/conv_first_round5.md: 56.7 us without a single
+// store, 63.1 without an MFMA, 31.0 with neither; a start stagger of the CU's three workgroups made it slower).  Kept for what it is:
+//   * halo loads through a buffer descriptor per image: 32-bit per-thread offsets, and for tiles whose halo lies inside the image
+//     (92 % at 1024 x 1024) the offset is a per-thread CONSTANT + a per-tile scalar (soffset) - no reflection arithmetic;
+//   * two halo images in LDS (alternating per tile; the loop body exists once per parity, so every LDS address is a per-lane
+//     register + an immediate) in front of the waves' private row buffers: ONE barrier per tile instead of three, and the next
+//     tile's halo is written before this tile's stores are issued;
+//   * stores through a descriptor per output ROW that starts at the tile's first pixel of that row and ends at the row's end: the
+//     hardware range check drops the pixels right of the image, rows below it are skipped wave-uniformly - no per-lane bounds
+//     selects, offsets = two per-lane constants + immediates;
+//   * the weights are consumed before the loop (their waits used to sit at their first use INSIDE it, where in every later tile
+//     they waited for the previous tile's stores to be acknowledged).
+constexpr int CF_HBUF = 1024;    // floats per halo image slot (3 planes x 340 = 1020)
 template <bool U8>
 __global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restrict__ img_any,
                                                             float* __restrict__ out, const float* __restrict__ wpk,
                                                             const float* __restrict__ bias, int H, int W, int tiles_x,
                                                             int tiles_y, int ntiles) {
-    const float* __restrict__ img_nchw = (const float*)img_any;
-    const uint8_t* __restrict__ img_u8 = (const uint8_t*)img_any;
     constexpr int HALO = 10 * 34;
-    // the halo image (3 planes of 340 floats) and the four waves' row buffers (4 x 8.5 KiB) share the allocation: 34 KiB
-    __shared__ __attribute__((aligned(16))) float smem[4 * 32 * CF_OSTR];
-    static_assert(HALO * 3 <= 4 * 32 * CF_OSTR, "LDS layout");
+    __shared__ __attribute__((aligned(16))) float smem_all[2 * CF_HBUF + 4 * 32 * CF_OSTR];
+    static_assert(HALO * 3 <= CF_HBUF, "LDS layout");
+    (void)bias;                                      // folded into K (pack_conv_first_kernel)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,57 +108,89 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restri
     const int tiles = tiles_x * tiles_y;
     const size_t plane = (size_t)H * W;
     const bool second = tid + 256 < HALO;          // threads 0..83 own a second halo pixel
+    constexpr int EB = U8 ? 3 : 4;                 // bytes between horizontally neighbouring source elements
+    // this thread's halo pixels p = tid, tid + 256: position in the 10 x 34 halo and offset from the halo's first pixel in the image
+    const int hy0 = tid / 34, hx0 = tid - hy0 * 34, hy1 = (tid + 256) / 34, hx1 = tid + 256 - hy1 * 34;
+    const int rel0 = (hy0 * W + hx0) * EB, rel1 = (hy1 * W + hx1) * EB;
+    const unsigned img_bytes = (unsigned)min((size_t)0xfffffff0u, plane * 3 * (U8 ? 1 : 4));
 
-    // halo pixels p = tid and tid + 256 of tile t -> registers
+    // halo pixels of tile t -> registers (raw bytes as integer bit patterns for U8: the loads stay in flight until the LDS store)
     f32x4 h0, h1;
     auto halo_load = [&](int t) {
         const int pt = t % tiles, img = t / tiles;
         const int tx0 = (pt % tiles_x) * 32, ty0 = (pt / tiles_x) * 8;
-        auto pixel = [&](int p) {
-            const int hy = p / 34, hx = p - hy * 34;
-            const size_t at = (size_t)reflect1(ty0 + hy - 1, H) * W + reflect1(tx0 + hx - 1, W);
-            if constexpr (U8) {      // raw bytes stay in the registers (as integer bit patterns) until the LDS store: the loads stay in flight
-                const uint8_t* __restrict__ q = img_u8 + ((size_t)img * plane + at) * 3;
-                return f32x4{__uint_as_float((unsigned)q[0]), __uint_as_float((unsigned)q[1]), __uint_as_float((unsigned)q[2]), 0.f};
+        const rsrc_t src = make_rsrc((const char*)img_any + (size_t)img * plane * 3 * (U8 ? 1 : 4), img_bytes);
+        const bool interior = ty0 >= 1 && ty0 + 9 <= H && tx0 >= 1 && tx0 + 33 <= W;       // wave-uniform
+        auto fetch = [&](int voff, int soff) {
+            if constexpr (U8) {
+                return f32x4{__uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b8(src, voff, soff, 0)),
+                             __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b8(src, voff + 1, soff, 0)),
+                             __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b8(src, voff + 2, soff, 0)), 0.f};
             } else {
-                const float* __restrict__ q = img_nchw + (size_t)img * 3 * plane + at;
-                return f32x4{q[0], q[plane], q[2 * plane], 0.f};
+                const int pb = (int)(plane * 4);      // (images of 2 GiB per plane are refused by the launcher)
+                return f32x4{__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src, voff, soff, 0)),
+                             __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src, voff, soff + pb, 0)),
+                             __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src, voff, soff + 2 * pb, 0)), 0.f};
             }
         };
-        h0 = pixel(tid);
-        if (second) h1 = pixel(tid + 256);
+        if (interior) {
+            const int soff = ((ty0 - 1) * W + tx0 - 1) * EB;
+            h0 = fetch(rel0, soff);
+            if (second) h1 = fetch(rel1, soff);
+        } else {
+            auto at = [&](int hy, int hx) { return (reflect1(ty0 + hy - 1, H) * W + reflect1(tx0 + hx - 1, W)) * EB; };
+            h0 = fetch(at(hy0, hx0), 0);
+            if (second) h1 = fetch(at(hy1, hx1), 0);
+        }
+    };
+    // halo registers -> LDS image `buf` (planar [r | g | b][10][34]: the K reads walk consecutive floats)
+    auto halo_to_lds = [&](float* buf) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if constexpr (U8) {                          // ToTensor: float(v) / 255, correctly rounded
+                buf[c * HALO + tid] = __fdiv_rn((float)__float_as_uint(h0[c]), 255.0f);
+                if (second) buf[c * HALO + tid + 256] = __fdiv_rn((float)__float_as_uint(h1[c]), 255.0f);
+            } else {
+                buf[c * HALO + tid] = h0[c];
+                if (second) buf[c * HALO + tid + 256] = h1[c];
+            }
+        }
     };
 
     int t = blockIdx.x;
     if (t >= ntiles) return;
     halo_load(t);
-    // this lane's 2 x 14 weights (A operand; K index e = 2 g + lh) and the LDS offset of halo element e = (tap, channel): held
-    // in registers over the tile walk
+    // this lane's 2 x 14 weights (A operand; K index e = 2 g + lh) and the LDS index of halo element e = (tap, channel) for this
+    // lane's pixel column in the wave's first row: held in registers over the tile walk
     float wf[2][14];
-    int koff[14];
+    int ka[14];
 #pragma unroll
     for (int g = 0; g < 14; ++g) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) wf[c][g] = wpk[(c * 14 + g) * 64 + lane];
         const int e = min(2 * g + lh, 26), tap = e / 3;
-        koff[g] = (e % 3) * HALO + (tap / 3) * 34 + tap % 3;
+        ka[g] = (e % 3) * HALO + (tap / 3) * 34 + tap % 3 + wave * 2 * 34 + li;
     }
-    for (;;) {
+#pragma unroll
+    for (int g = 0; g < 14; ++g)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) asm volatile("" ::"v"(wf[c][g]));       // arrived BEFORE the loop (see above)
+    halo_to_lds(smem_all);
+    float* const st = smem_all + 2 * CF_HBUF + wave * (32 * CF_OSTR);        // this wave's row buffer
+    // per-lane constants of the epilogue: where this lane's four channels of pixel li go in the row buffer, which 16 bytes of the
+    // row buffer it reads back (pixel 4 k + lane / 16, quad lane % 16) and where those go in the output row
+    float* const st_w = st + li * CF_OSTR + 4 * lh;
+    const float* const st_r = st + (lane >> 4) * CF_OSTR + (lane & 15) * 4;
+    const int vo = ((lane >> 4) * 64 + (lane & 15) * 4) * 4;
+
+    auto tile_body = [&](auto PAR) -> bool {
+        constexpr int par = decltype(PAR)::value;
+        const float* const halo = smem_all + par * CF_HBUF;
         const int pt = t % tiles, img = t / tiles;
         const int tx0 = (pt % tiles_x) * 32, ty0 = (pt / tiles_x) * 8;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {                    // planar [r | g | b][10][34]: the K reads below walk consecutive floats
-            if constexpr (U8) {                          // ToTensor: float(v) / 255, correctly rounded
-                smem[c * HALO + tid] = __fdiv_rn((float)__float_as_uint(h0[c]), 255.0f);
-                if (second) smem[c * HALO + tid + 256] = __fdiv_rn((float)__float_as_uint(h1[c]), 255.0f);
-            } else {
-                smem[c * HALO + tid] = h0[c];
-                if (second) smem[c * HALO + tid + 256] = h1[c];
-            }
-        }
-        __syncthreads();
+        __syncthreads();                                 // halo image `par` is complete (and image 1 - par is free, see above)
         const int tn = t + gridDim.x;
-        if (tn < ntiles) halo_load(tn);                  // in flight during this tile's MFMAs and stores
+        if (tn < ntiles) halo_load(tn);                  // in flight during this tile's MFMAs
 
         f32x16 acc[2][2];      // [channel tile][row of this wave]
 #pragma unroll
@@ -159,7 +204,7 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restri
             float xf[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                xf[m] = smem[(wave * 2 + m) * 34 + li + koff[g]];
+                xf[m] = halo[ka[g] + m * 34];
                 if (g == 13) xf[m] = lh ? 1.0f : xf[m];                       // e = 27: the bias row
             }
 #pragma unroll
@@ -167,47 +212,47 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restri
 #pragma unroll
                 for (int m = 0; m < 2; ++m) acc[c][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[c][g], xf[m], acc[c][m], 0, 0, 0);
         }
-        __syncthreads();                                 // every wave has read its halo pixels: the row buffers may overwrite them
-
-        float* const st = smem + wave * (32 * CF_OSTR);
-        // the output descriptor starts at the tile's first row: offsets stay inside 8 rows, the image may be of any size
-        const size_t oleft = (size_t)(H - ty0) * W * 256;
-        const rsrc_t dst = make_rsrc(out + ((size_t)img * H + ty0) * W * 64, oleft < 0x7ffffff0ull ? (unsigned)oleft : 0x7ffffff0u);
+        // the next tile's halo goes to the OTHER LDS image here, before this tile's stores are issued (loads and stores share one
+        // in-flight counter on gfx9: consumed later, the prefetched loads would wait for every store issued in between)
+        if (tn < ntiles) halo_to_lds(smem_all + (1 - par) * CF_HBUF);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const int ry = wave * 2 + m, y = ty0 + ry;
+            const int y = ty0 + wave * 2 + m;            // wave-uniform
             // lane (li, lh) holds channels 32 c + 8 q + 4 lh + (0..3) of pixel li in acc[c][m][4 q .. 4 q + 3]
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int ch = 32 * c + 8 * q + 4 * lh;
                     f32x4 v;
 #pragma unroll
                     // ReLU as ONE instruction: max over the BIT PATTERNS as signed integers (negative floats, -0 and negative NaNs are
                     // negative integers -> +0; everything else unchanged: fmaxf(x, 0) for every x).  fmaxf itself costs two v_max
-                    // here - accumulators straight out of an MFMA get a canonicalising v_max(x, x) first - and every vector
-                    // instruction takes matrix-pipe time on this chip.  (The bias came in through K.)
+                    // here - accumulators straight out of an MFMA get a canonicalising v_max(x, x) first.  (The bias came in through K.)
                     for (int e = 0; e < 4; ++e) {
-                        const float x = acc[c][m][4 * q + e];
-                        const int xi = __float_as_int(x);
+                        const int xi = __float_as_int(acc[c][m][4 * q + e]);
                         v[e] = __int_as_float(xi > 0 ? xi : 0);
                     }
-                    *(f32x4*)(st + li * CF_OSTR + ch) = v;
+                    *(f32x4*)(st_w + 32 * c + 8 * q) = v;
                 }
-            // the row buffer is private to the wave and LDS operations of one wave complete in order: no barrier
+            if (y < H) {
+                // this output row from the tile's first pixel to the END OF THE ROW: pixels right of the image fall outside the
+                // descriptor and are dropped by the hardware; the row buffer is private to the wave and LDS operations of one wave
+                // complete in order: no barrier
+                const rsrc_t dst = make_rsrc(out + (((size_t)img * H + y) * W + tx0) * 64, (unsigned)(W - tx0) * 256u);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int idx = k * 64 + lane, px = idx >> 4, q16 = idx & 15;
-                const f32x4 v = *(const f32x4*)(st + px * CF_OSTR + q16 * 4);
-                const int x = tx0 + px;
-                const int off = ((ry * W + x) * 64 + q16 * 4) * 4;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, (y < H && x < W) ? off : 0x7fffffff, 0, 0);
+                for (int k = 0; k < 8; ++k) {
+                    const f32x4 v = *(const f32x4*)(st_r + 4 * k * CF_OSTR);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, vo + k * 1024, 0, 0);
+                }
             }
         }
-        if (tn >= ntiles) break;
+        if (tn >= ntiles) return false;
         t = tn;
-        __syncthreads();                                 // the row buffers have been read: the next halo may overwrite them
+        return true;
+    };
+    for (;;) {
+        if (!tile_body(std::integral_constant<int, 0>{})) break;
+        if (!tile_body(std::integral_constant<int, 1>{})) break;
     }
 }
 
@@ -342,6 +387,7 @@ int launch_conv_first(const void* img, int u8, float* out, const float* packed, 
                       hipStream_t s) {
     if (H < 2 || W < 2 || n < 1) { set_error("conv_first: H, W must be >= 2, got %dx%d", H, W); return -1; }
     if ((size_t)W * 256 * 8 >= 0x7ffffff0ULL) { set_error("conv_first: eight 64-channel rows of width %d reach 2 GiB", W); return -1; }
+    if ((size_t)H * W * 12 >= 0x7ffffff0ULL) { set_error("conv_first: an image of %d x %d pixels reaches 2 GiB as three float planes", H, W); return -1; }
     const int tx = (W + 31) / 32, ty = (H + 7) / 8;
     const long long ntiles = (long long)tx * ty * n;
     if (ntiles > 0x7fffffffLL) { set_error("conv_first: bad grid"); return -1; }
