@@ -12,6 +12,8 @@
 namespace adain {
 
 static thread_local char g_err[512] = "";
+// launch schedule of the calling thread (adain_set_schedule): ADAIN_SCHEDULE_BATCH or ADAIN_SCHEDULE_LATENCY
+static thread_local int g_schedule = ADAIN_SCHEDULE_BATCH;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -100,7 +102,7 @@ static int pack_layer(const float* w, float* dst, int cin, int cout, hipStream_t
     return launch_pack_wino4(w, dst, cin, cout, s);
 }
 
-static int launch_layer(ConvArgs& a, const float* packed, const Offsets& f, int i, int src, hipStream_t s) {
+static int launch_layer(ConvArgs& a, const float* packed, const Offsets& f, int i, int src, hipStream_t s, SplitWs split = SplitWs{nullptr, 0}) {
     a.bias = packed + f.b[i];
     a.wpk = packed + f.w[i];
 #ifdef ADAIN_DIAG
@@ -111,7 +113,7 @@ static int launch_layer(ConvArgs& a, const float* packed, const Offsets& f, int 
     }
     if (conv_form() == FORM_DIRECT) return launch_conv3x3(a, src, -1, s);
 #endif
-    return launch_conv3x3_wino4(a, src, s);
+    return launch_conv3x3_wino4(a, src, s, split);
 }
 
 static int copy_bias(const float* src, float* dst, int n, hipStream_t s) {
@@ -136,6 +138,14 @@ extern "C" {
 
 int adain_abi_version(void) { return ADAIN_ABI_VERSION; }
 const char* adain_last_error(void) { return g_err; }
+
+int adain_set_schedule(int schedule) {
+    if (schedule != ADAIN_SCHEDULE_BATCH && schedule != ADAIN_SCHEDULE_LATENCY) { set_error("set_schedule: unknown schedule %d", schedule); return ADAIN_EINVAL; }
+    const int prev = g_schedule;
+    g_schedule = schedule;
+    return prev;
+}
+int adain_get_schedule(void) { return g_schedule; }
 
 size_t adain_encoder_packed_floats(void) { return enc_offsets().total; }
 size_t adain_decoder_packed_floats(void) { return dec_offsets().total; }
@@ -188,10 +198,36 @@ static void enc_buf_sizes(int n, int h, int w, size_t* a_floats, size_t* b_float
 }
 static size_t enc_buf_a(int n, int h, int w) { size_t a, b; enc_buf_sizes(n, h, w, &a, &b); return a; }
 static size_t enc_buf_b(int n, int h, int w) { size_t a, b; enc_buf_sizes(n, h, w, &a, &b); return b; }
+// Third block of an encoder / decoder workspace: the partial-sum slabs of the layers that ADAIN_SCHEDULE_LATENCY would split along
+// cin (conv_wino4.hip: only launches with fewer tiles than compute units - single frames of the 256 class; at most 8 MB).  Always
+// part of the workspace, whatever the calling thread's schedule is when it asks for the size.
+static size_t enc_slab_floats(int n, int h, int w) {
+    size_t mx = 0;
+    int ch = h, cw = w;
+    for (int l = 0; l < 8; ++l) {
+        const size_t f = wino4_split_floats(n, ch, cw, ENC[l].cin, ENC[l].cout);
+        if (f > mx) mx = f;
+        if (ENC[l].pool) { ch = (ch + 1) / 2; cw = (cw + 1) / 2; }
+    }
+    return align64(mx);
+}
+static size_t dec_slab_floats(int n, int hc, int wc) {
+    size_t mx = 0;
+    int ch = hc, cw = wc;
+    for (int l = 0; l < 8; ++l) {
+        if (DEC[l].src == SRC_UP2X) { ch *= 2; cw *= 2; }
+        const size_t f = wino4_split_floats(n, ch, cw, DEC[l].cin, DEC[l].cout);
+        if (f > mx) mx = f;
+    }
+    return align64(mx);
+}
+static SplitWs split_ws(float* slab, size_t floats) {
+    return (g_schedule == ADAIN_SCHEDULE_LATENCY && floats) ? SplitWs{slab, floats} : SplitWs{nullptr, 0};
+}
 
 size_t adain_encode_workspace_bytes(int n, int h, int w) {
     if (n < 1 || h < 1 || w < 1) return 0;
-    return (enc_buf_a(n, h, w) + enc_buf_b(n, h, w)) * sizeof(float);
+    return (enc_buf_a(n, h, w) + enc_buf_b(n, h, w) + enc_slab_floats(n, h, w)) * sizeof(float);
 }
 
 size_t adain_encode_multi_workspace_bytes(int count, const int* n, const int* h, const int* w) {
@@ -332,6 +368,7 @@ static int encode_impl(int count, const void* const* images, int u8, float* cons
     const Offsets f = enc_offsets();
     float* bufA[MAX_CONV_SEGS];
     float* bufB[MAX_CONV_SEGS];
+    SplitWs split[MAX_CONV_SEGS];
     const float* cur[MAX_CONV_SEGS];
     int ch[MAX_CONV_SEGS], cw[MAX_CONV_SEGS];
     float* base = (float*)workspace;
@@ -344,6 +381,8 @@ static int encode_impl(int count, const void* const* images, int u8, float* cons
         bufA[i] = base;
         bufB[i] = base + enc_buf_a(n[i], h[i], w[i]);
         base = bufB[i] + enc_buf_b(n[i], h[i], w[i]);
+        split[i] = split_ws(base, enc_slab_floats(n[i], h[i], w[i]));
+        base += enc_slab_floats(n[i], h[i], w[i]);
         if (frame_major) {
             RET_IF(encode_frame_major(images[i], u8, n[i], h[i], w[i], frame_major, packed, f, bufA[i], bufB[i], &cur[i], &ch[i], &cw[i], s));
             continue;
@@ -367,7 +406,7 @@ static int encode_impl(int count, const void* const* images, int u8, float* cons
             // one launch for every batch: the persistent kernel's tile list runs over all of them (csrc/conv_wino4.hip, SEGMENTS)
             a.bias = packed + f.b[l];
             a.wpk = packed + f.w[l];
-            RET_IF(launch_conv3x3_wino4_multi(a, segs, count, ENC[l].src, s));
+            RET_IF(launch_conv3x3_wino4_multi(a, segs, count, ENC[l].src, s, split));
         } else {
             for (int i = 0; i < count; ++i) {
                 a.in = segs[i].in; a.out = segs[i].out; a.n = n[i];
@@ -412,7 +451,7 @@ int adain_encode_relu1_1(const void* image, int is_u8, float* relu1_1, const flo
 
 size_t adain_decode_workspace_bytes(int n, int hc, int wc) {
     if (n < 1 || hc < 1 || wc < 1) return 0;
-    return (align64((size_t)n * hc * wc * 1024) + align64((size_t)n * hc * wc * 4096)) * sizeof(float);
+    return (align64((size_t)n * hc * wc * 1024) + align64((size_t)n * hc * wc * 4096) + dec_slab_floats(n, hc, wc)) * sizeof(float);
 }
 
 int adain_decode(const float* feat, float* image, const float* packed, void* workspace, size_t ws_bytes, int n, int hc,
@@ -425,6 +464,7 @@ int adain_decode(const float* feat, float* image, const float* packed, void* wor
     // buffer A (1024*hc*wc floats per image) takes the outputs of layers 0,2,4,6; buffer B (4096*hc*wc) of 1,3,5,7
     float* bufA = (float*)workspace;
     float* bufB = bufA + align64((size_t)n * hc * wc * 1024);
+    const SplitWs split = split_ws(bufB + align64((size_t)n * hc * wc * 4096), dec_slab_floats(n, hc, wc));
     const float* cur = feat;
     int ch = hc, cw = wc;
     record(ev, 0, s);
@@ -442,7 +482,7 @@ int adain_decode(const float* feat, float* image, const float* packed, void* wor
         a.H = ch; a.W = cw;
         a.cin = DEC[i].cin; a.cout = DEC[i].cout;
         a.relu = 1;
-        RET_IF(launch_layer(a, packed, f, i, DEC[i].src, s));
+        RET_IF(launch_layer(a, packed, f, i, DEC[i].src, s, split));
         record(ev, i + 1, s);
         cur = a.out;
     }
@@ -707,6 +747,19 @@ int adain_conv3x3_wino(const float* in, float* out, const float* packed_w, const
     set_error("conv3x3_wino: form %d exists in the diagnostic library only (this library runs form 5, F(4,3) x F(2,3))", mh);
     return ADAIN_EINVAL;
 #endif
+}
+
+size_t adain_conv3x3_wino4_split_workspace_bytes(int n, int h, int w, int cin, int cout) {
+    return wino4_split_floats(n, h, w, cin, cout) * sizeof(float);
+}
+
+int adain_conv3x3_wino4_split(const float* in, float* out, const float* packed_w, const float* bias, int n, int h, int w, int hs, int ws,
+                              int cin, int cout, int src_mode, int relu, int pool_out, void* workspace, size_t ws_bytes, adain_stream_t stream) {
+    if (!in || !out || !packed_w || !bias) { set_error("conv3x3_wino4_split: null pointer"); return ADAIN_EINVAL; }
+    ConvArgs a{};
+    a.in = in; a.out = out; a.wpk = packed_w; a.bias = bias;
+    a.n = n; a.H = h; a.W = w; a.Hs = hs; a.Ws = ws; a.cin = cin; a.cout = cout; a.relu = relu; a.pool_out = pool_out ? 1 : 0;
+    return launch_conv3x3_wino4(a, src_mode, (hipStream_t)stream, SplitWs{(float*)workspace, workspace ? ws_bytes / sizeof(float) : 0});
 }
 
 #ifdef ADAIN_DIAG

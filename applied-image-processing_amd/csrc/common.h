@@ -29,6 +29,16 @@ struct ConvArgs {
     int xcd_order;      // 1: XCD-aware block -> tile order (speed only)
     int tiles_x, tiles_y;
     unsigned long long* dbg;   // diagnostic builds only (clock stamps); nullptr in production
+    // cin split of the F(4,3) x F(2,3) one-tile form (set by launch_conv3x3_wino4 only): workgroups per (tile, channel tile),
+    // input channels per workgroup, floats between the partial-sum slabs that `out` then points at
+    int ksplit, cin_sub;
+    size_t slab_stride;
+};
+
+// Partial-sum slabs for a cin-split launch of the F(4,3) x F(2,3) kernel (caller-owned workspace; slab == nullptr: never split).
+struct SplitWs {
+    float* slab;
+    size_t floats;
 };
 
 // One (source, output) tensor pair of a multi-segment launch of the persistent F(4,3) x F(2,3) kernel: the segments of one
@@ -88,10 +98,16 @@ inline int device_cu_count() {
 
 // conv_wino4.hip: F(4,3) x F(2,3) form (its own packed-weight layout, 24 floats per weight pair)
 int launch_pack_wino4(const float* w_oihw, float* packed, int cin, int cout, hipStream_t s);
-int launch_conv3x3_wino4(const ConvArgs& a, int src_mode, hipStream_t s);
+// split: workspace for the cin split of a launch too small to give every compute unit a tile (see wino4_split_floats); without
+// one the launch is never split
+int launch_conv3x3_wino4(const ConvArgs& a, int src_mode, hipStream_t s, SplitWs split = SplitWs{nullptr, 0});
 // the same layer over `count` tensor pairs (sizes / addresses from segs[i]: in, out, n, H, W, Hs, Ws; the rest from `layer`):
 // one persistent launch whose tile list covers every segment when there is enough work, one launch per segment otherwise
-int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int count, int src_mode, hipStream_t s);
+// (split[i]: segment i's slab workspace for that case, or nullptr)
+int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int count, int src_mode, hipStream_t s,
+                               const SplitWs* split = nullptr);
+// floats of slab workspace a launch of this layer over n images of H x W (conv output size) needs to be split; 0: it would not be
+size_t wino4_split_floats(int n, int H, int W, int cin, int cout);
 double wino4_rounds_per_image(int H, int W, int cout);      // persistent-grid rounds one image of a layer is worth (schedules, api.hip)
 // conv_wino3.hip
 int launch_conv3x3_wino3(const ConvArgs& a, int src_mode, hipStream_t s);

@@ -174,6 +174,11 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     // geometry of the tile being computed (gH, gW: conv output size; gWs: source row length) and of its tensors
     int gH = a.H, gW = a.W, gWs = a.Ws, gtx = a.tiles_x;
     int seg = 0;                                     // persistent form: segment of the current tile
+    // CIN SPLIT (one-tile form only, launches too small to give every compute unit a tile: launch_conv3x3_wino4): workgroup
+    // (tile, channel tile, ks) accumulates input channels [ks * cin_sub, (ks + 1) * cin_sub) only and writes its output-transformed
+    // partial sums - no bias, no ReLU, no pool - into slab ks of a workspace; splitk_combine_kernel adds the slabs in the fixed
+    // order ks = 0, 1, ... and finishes the layer.  The output transform is linear, so the split changes rounding only.
+    int ks = 0;
     auto seg_of = [&](int it) {
         int si = 0;
         for (int k = 1; k < m.count; ++k)
@@ -216,11 +221,12 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         img = lid / nct;
     } else {                         // channel tile fastest: they share halos
         ct = lid % nct; lid /= nct;
+        if (a.ksplit > 1) { ks = lid % a.ksplit; lid /= a.ksplit; }      // CIN SPLIT: then the cin ranges of one (pixel tile, channel tile)
         pt = lid % tiles;
         img = lid / tiles;
     }
     int tx0 = (pt % gtx) * TILE_W, ty0 = (pt / gtx) * TILE_H;
-    const int nst = a.cin / W4_KR;
+    const int nst = (PERSIST ? a.cin : a.cin_sub) / W4_KR;      // stages of this workgroup's cin range
     const int nch = a.cin / 8;
 
     // BIG: per-tile buffer descriptors.  The source descriptor starts at the first source row a tile's halo can touch, the output
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
                 roff[k] = ((y * Ws + x) * a.cin + q * 4) * 4;
             }
             roff_seg = -1;
-            tbase = 0;
+            tbase = PERSIST ? 0 : ks * a.cin_sub * 4;       // first channel of this workgroup's cin range
         }
     };
     halo_offsets(tx0, ty0, gH, gW, gWs, seg);
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     // RING12 (experiment, DIAG 12): two chunks of weight slots - a chunk's six fragments are requested during the previous chunk
     constexpr bool RING12 = DIAG == 12;
     f32x4 bq[RING12 ? 12 : 6];
-    int wso = ((ct * 4 + wj) * nch) * 6144;
+    int wso = ((ct * 4 + wj) * nch + (PERSIST ? 0 : ks * (a.cin_sub >> 3))) * 6144;
 #pragma unroll
     for (int r = 0; r < (RING12 ? 6 : 4); ++r) bq[r] = buf_load4(wsr, wvo, wso + r * 1024);
 
@@ -365,9 +371,10 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
         const int le = lane_now(), q8 = le & 7, tt = le >> 3;
         const int tl = wj * 8 + tt;
         const float* Pr = smem + tl * 32 + ((q8 ^ ((tl >> 1) & 7)) << 2);
-        const f32x4 bias4 = *(const f32x4*)(a.bias + ct * 32 + 4 * q8);
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (PERSIST || a.ksplit <= 1) bias4 = *(const f32x4*)(a.bias + ct * 32 + 4 * q8);      // (a split launch's bias is the combine kernel's)
         const int eH = PERSIST ? m.s[seg].H : a.H, eW = PERSIST ? m.s[seg].W : a.W;
-        float* const eout = PERSIST ? m.s[seg].out : a.out;
+        float* const eout = PERSIST ? m.s[seg].out : a.out + (size_t)ks * a.slab_stride;         // slab_stride = 0 unless split
         const int Ho = a.pool_out ? (eH + 1) >> 1 : eH, Wo = a.pool_out ? (eW + 1) >> 1 : eW;
         rsrc_t dst;
         if constexpr (!BIG) {
@@ -728,6 +735,48 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     }
 }
 
+// Second half of a cin-split layer: out = [pool](relu(slab 0 + slab 1 + ... + bias)), the slabs added in that fixed order (bitwise
+// reproducible; no atomics).  One thread per output pixel and channel quad; slabs and out are NHWC, the slabs at the conv's
+// own size H x W, out at the pooled size when `pool` (MaxPool2d(2, 2, ceil_mode=True): windows clipped at the border).
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ slabs, size_t slab_stride, int S,
+                                                             const float* __restrict__ bias, int relu, int pool, float* __restrict__ out,
+                                                             int n, int H, int W, int cout) {
+    const int Ho = pool ? (H + 1) >> 1 : H, Wo = pool ? (W + 1) >> 1 : W;
+    const int cq = cout >> 2;
+    const size_t total = (size_t)n * Ho * Wo * cq;
+    const float lo = relu ? 0.f : -__builtin_inff();
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t t = idx;
+        const int c4 = (int)(t % cq); t /= cq;
+        const int xo = (int)(t % Wo); t /= Wo;
+        const int yo = (int)(t % Ho);
+        const int img = (int)(t / Ho);
+        const f32x4 b4 = *(const f32x4*)(bias + 4 * c4);
+        auto at = [&](int y, int x) {
+            const float* p = slabs + (((size_t)img * H + y) * W + x) * cout + 4 * c4;
+            f32x4 v = *(const f32x4*)p;
+            for (int k = 1; k < S; ++k) v += *(const f32x4*)(p + (size_t)k * slab_stride);
+            v += b4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, __builtin_inff());
+            return v;
+        };
+        f32x4 r;
+        if (pool) {
+            const int y0 = 2 * yo, x0 = 2 * xo;
+            r = at(y0, x0);
+            if (x0 + 1 < W) r = max4(r, at(y0, x0 + 1));
+            if (y0 + 1 < H) {
+                r = max4(r, at(y0 + 1, x0));
+                if (x0 + 1 < W) r = max4(r, at(y0 + 1, x0 + 1));
+            }
+        } else {
+            r = at(yo, xo);
+        }
+        *(f32x4*)(out + idx * 4) = r;
+    }
+}
+
 int launch_pack_wino4(const float* w, float* p, int cin, int cout, hipStream_t s) {
     if (cin % 8 || cout % 32) { set_error("pack_wino4: cin %% 8 or cout %% 32 != 0 (%d, %d)", cin, cout); return -1; }
     const size_t total = (size_t)cin * cout * 24;
@@ -854,8 +903,32 @@ static void w4_launch(int src_mode, bool persist, bool big, int geo, dim3 grid, 
     }
 }
 
-int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
+// Cin split of a small launch.  A one-tile workgroup walks its whole cin loop alone (about 1.5 us per 16 channels, 8 us of launch,
+// prologue and epilogue around it: tools/probes/small_frame_trace.py), and a workgroup's vector and matrix instructions share the
+// SIMD's issue, so a second workgroup on a compute unit buys nothing: what a split can win is the compute units a launch leaves
+// EMPTY.  S = the largest power of two with items x S <= compute units and at least 64 channels (4 stages) per workgroup.
+static int wino4_ksplit(long long items, int cin) {
+    const int cus = device_cu_count();
+    int S = 1;
+    while (S < 8 && items * (2 * S) <= cus && cin % (2 * S * W4_KR) == 0 && cin / (2 * S) >= 64) S *= 2;
+    return S;
+}
+static long long wino4_items(int n, int H, int W, int cout, int* geo_out) {
+    ConvSeg sg{};
+    sg.n = n; sg.H = H; sg.W = W;
+    const int geo = pick_geo(&sg, 1);
+    if (geo_out) *geo_out = geo;
+    return geo_tiles(geo, n, H, W) * (cout / 32);
+}
+size_t wino4_split_floats(int n, int H, int W, int cin, int cout) {
+    if (n < 1 || H < 2 || W < 2 || cin % W4_KR || cout % 32) return 0;
+    const int S = wino4_ksplit(wino4_items(n, H, W, cout, nullptr), cin);
+    return S > 1 ? (size_t)S * n * H * W * cout : 0;
+}
+
+int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s, SplitWs split) {
     ConvArgs a = a0;
+    a.ksplit = 1; a.cin_sub = a.cin; a.slab_stride = 0;
     if (check_wino4_shape(a, src_mode)) return -1;
     ConvSegs m{};
     m.count = 1;
@@ -904,11 +977,27 @@ int launch_conv3x3_wino4(const ConvArgs& a0, int src_mode, hipStream_t s) {
         return check_launch("conv3x3_wino4(diag)");
     }
 #endif
+    const int S = (split.slab && !big && !a.dbg) ? wino4_ksplit(blocks, a.cin) : 1;
+    if (S > 1) {
+        const size_t slab = (size_t)a.n * a.H * a.W * a.cout;
+        if (split.floats < (size_t)S * slab) { set_error("conv3x3_wino4: split workspace too small (%zu < %zu floats)", split.floats, (size_t)S * slab); return -1; }
+        ConvArgs p = a;                  // first half: S workgroups per (tile, channel tile), partial sums into the slabs
+        p.ksplit = S; p.cin_sub = a.cin / S; p.slab_stride = slab;
+        p.out = split.slab; p.relu = 0; p.pool_out = 0; p.xcd_order = 1;
+        w4_launch(src_mode, false, false, geo, dim3((unsigned)(blocks * S)), s, p, m, items * S, 0);
+        if (int r = check_launch("conv3x3_wino4(split)")) return r;
+        const int Ho = a.pool_out ? (a.H + 1) / 2 : a.H, Wo = a.pool_out ? (a.W + 1) / 2 : a.W;
+        const size_t total = (size_t)a.n * Ho * Wo * (a.cout / 4);
+        const unsigned cb = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(splitk_combine_kernel, dim3(cb), dim3(256), 0, s, (const float*)split.slab, slab, S, a.bias, a.relu, a.pool_out, a.out,
+                           a.n, a.H, a.W, a.cout);
+        return check_launch("conv3x3_wino4(combine)");
+    }
     w4_launch(src_mode, false, big, geo, g, s, a, m, items, 0);
     return check_launch("conv3x3_wino4");
 }
 
-int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int count, int src_mode, hipStream_t s) {
+int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int count, int src_mode, hipStream_t s, const SplitWs* split) {
     if (count < 1 || count > MAX_CONV_SEGS) { set_error("conv3x3_wino4_multi: 1..%d segments, got %d", MAX_CONV_SEGS, count); return -1; }
     ConvSegs m{};
     m.count = count;
@@ -944,7 +1033,7 @@ int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int c
         for (int i = 0; i < count; ++i) {
             a.in = segs[i].in; a.out = segs[i].out; a.n = segs[i].n;
             a.H = segs[i].H; a.W = segs[i].W; a.Hs = segs[i].Hs; a.Ws = segs[i].Ws;
-            if (int r = launch_conv3x3_wino4(a, src_mode, s)) return r;
+            if (int r = launch_conv3x3_wino4(a, src_mode, s, split ? split[i] : SplitWs{nullptr, 0})) return r;
         }
         return 0;
     }

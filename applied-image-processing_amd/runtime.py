@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_PKG, "libadain_hip.so")
 DIAG_LIB_PATH = os.path.join(_PKG, "libadain_hip_diag.so")
 
 SRC_DIRECT, SRC_UP2X, SRC_POOL2 = 0, 1, 2
-ABI_VERSION = 3          # ADAIN_ABI_VERSION of include/adain_hip.h this binding was written against
+SCHEDULE_BATCH, SCHEDULE_LATENCY = 0, 1      # ADAIN_SCHEDULE_*: see adain_set_schedule in include/adain_hip.h
+ABI_VERSION = 4          # ADAIN_ABI_VERSION of include/adain_hip.h this binding was written against
 
 _c_int, _c_float, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 _PP = ctypes.POINTER(ctypes.c_void_p)
@@ -27,6 +28,8 @@ _PP = ctypes.POINTER(ctypes.c_void_p)
 SIGNATURES = {
     "adain_abi_version": (_c_int, []),
     "adain_last_error": (ctypes.c_char_p, []),
+    "adain_set_schedule": (_c_int, [_c_int]),
+    "adain_get_schedule": (_c_int, []),
     "adain_encoder_packed_floats": (_c_size_t, []),
     "adain_decoder_packed_floats": (_c_size_t, []),
     "adain_encoder_pack": (_c_int, [_PP, _PP, _c_void_p, _c_void_p]),
@@ -68,6 +71,8 @@ SIGNATURES = {
     "adain_conv3x3_wino4_packed_floats": (_c_size_t, [_c_int, _c_int]),
     "adain_conv3x3_wino4_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
     "adain_conv3x3_wino": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 11 + [_c_void_p]),
+    "adain_conv3x3_wino4_split_workspace_bytes": (_c_size_t, [_c_int] * 5),
+    "adain_conv3x3_wino4_split": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 10 + [_c_void_p, _c_size_t, _c_void_p]),
 }
 
 # entry points of include/adain_hip_diag.h: exported by the diagnostic library only
@@ -133,6 +138,35 @@ def _check(rc, what):
     ABI_CALLS[0] += 1
     if rc != 0:
         raise AdainHipError(f"{what} failed ({rc}): {lib().adain_last_error().decode()}")
+
+
+class schedule:
+    """``with runtime.schedule(runtime.SCHEDULE_LATENCY): ...`` - the launch schedule of the calling thread for the C-ABI calls
+    inside (adain_set_schedule: under LATENCY a generic 3x3 layer whose launch leaves compute units without a tile is split along
+    cin; results then differ from the batch schedule's in the last bits and depend on the launch's batch size).  Restored on exit."""
+
+    def __init__(self, value):
+        self.value = int(value)
+
+    def __enter__(self):
+        self.prev = set_schedule(self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_schedule(self.prev)
+        return False
+
+
+def set_schedule(value):
+    """Sets the calling thread's schedule; returns the previous one."""
+    prev = lib().adain_set_schedule(int(value))
+    if prev < 0:
+        raise AdainHipError(f"adain_set_schedule failed ({prev}): {lib().adain_last_error().decode()}")
+    return prev
+
+
+def get_schedule():
+    return lib().adain_get_schedule()
 
 
 def _stream():
@@ -627,4 +661,26 @@ def conv3x3_wino(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, p
     with torch.cuda.device(x.device):
         _check(lib().adain_conv3x3_wino(x.data_ptr(), out.data_ptr(), packed_w.data_ptr(), bias.data_ptr(), n, h, w, hs, ws_, cin, cout,
                                         src_mode, int(relu), int(pool_out), int(m_tiles), _stream()), "adain_conv3x3_wino")
+    return out
+
+
+def conv3x3_wino4_split_bytes(n, h, w, cin, cout):
+    """Bytes of partial-sum slabs a launch of this layer needs to be split along cin; 0: it would not be split."""
+    return lib().adain_conv3x3_wino4_split_workspace_bytes(int(n), int(h), int(w), int(cin), int(cout))
+
+
+def conv3x3_wino4_split(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, pool_out=False):
+    """The F(4,3) x F(2,3) layer as the latency schedule runs it: split along cin when the launch is smaller than the chip
+    (adain_conv3x3_wino4_split; weights packed by conv3x3_wino_pack(form=5))."""
+    x = _dev(x_nhwc, "x")
+    n, hs, ws_, cin = x.shape
+    h, w = (2 * hs, 2 * ws_) if src_mode == SRC_UP2X else (hs, ws_)
+    oh, ow = ((h + 1) // 2, (w + 1) // 2) if pool_out else (h, w)
+    out = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        nbytes = conv3x3_wino4_split_bytes(n, h, w, cin, cout)
+        ws = workspace(x.device, "conv_split", nbytes) if nbytes else None
+        _check(lib().adain_conv3x3_wino4_split(x.data_ptr(), out.data_ptr(), packed_w.data_ptr(), bias.data_ptr(), n, h, w, hs, ws_, cin, cout,
+                                               src_mode, int(relu), int(pool_out), ws.data_ptr() if ws is not None else None, nbytes, _stream()),
+               "adain_conv3x3_wino4_split")
     return out

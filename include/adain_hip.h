@@ -28,8 +28,10 @@ extern "C" {
 
 /* 2: adain_encode_u8, adain_u8_to_f32 and adain_stylize_u8* added; the direct / F(2x2,3x3) single-layer entry points moved to
  * the diagnostic library (include/adain_hip_diag.h); adain_conv3x3_wino accepts form 5 only.  Version 1 was never frozen.
- * 3: adain_encode_relu1_1 and the uint8 Pillow-exact resize (adain_resize_pil_bilinear_u8*) added; nothing removed or changed. */
-#define ADAIN_ABI_VERSION 3
+ * 3: adain_encode_relu1_1 and the uint8 Pillow-exact resize (adain_resize_pil_bilinear_u8*) added; nothing removed or changed.
+ * 4: adain_set_schedule / adain_get_schedule and adain_conv3x3_wino4_split* added; the encoder / decoder / stylize workspaces grow by
+ *    the partial-sum slabs of the latency schedule (at most 8 MB; callers that size them with the *_bytes queries need no change). */
+#define ADAIN_ABI_VERSION 4
 #define ADAIN_OK 0
 #define ADAIN_EINVAL (-1)  /* bad argument / unsupported shape */
 #define ADAIN_ELAUNCH (-2) /* HIP reported a launch error */
@@ -47,6 +49,22 @@ typedef void* adain_stream_t; /* hipStream_t */
 
 ADAIN_API int adain_abi_version(void);
 ADAIN_API const char* adain_last_error(void);
+
+/* ---- launch schedule of the CALLING THREAD (enqueue-time state, like the error text; not captured by, and harmless to, hipGraphs) ----
+ * The reference's callers work at two operating points: loops that style ONE small frame per call (video/utils.py:261-270,341-350:
+ * adain_inference(content_size=256) per video frame; test.py:160: content_size 512 by default) and batch jobs.
+ *   ADAIN_SCHEDULE_BATCH (default): every generic 3x3 layer accumulates its input channels in one chain.  A frame's result does not
+ *     depend on the batch it is in: single-frame calls, sub-batches of any size and any sharding over GPUs give the same bits.
+ *   ADAIN_SCHEDULE_LATENCY: a layer whose launch has fewer tiles than the device has compute units (relu4-level layers of a single
+ *     256-class frame: 64-128 tiles for 256 compute units, each walking 256-512 input channels alone) is split along cin over
+ *     2-8 workgroups per tile; their output-transformed partial sums are added in a FIXED order by a second kernel (no atomics:
+ *     the same call gives the same bits every time).  Results differ from the batch schedule's in the last bits (shorter
+ *     accumulation chains: slightly closer to the exact sum) and, unlike it, depend on the launch's batch size.
+ * adain_set_schedule returns the previous value (>= 0) or ADAIN_EINVAL. */
+#define ADAIN_SCHEDULE_BATCH 0
+#define ADAIN_SCHEDULE_LATENCY 1
+ADAIN_API int adain_set_schedule(int schedule);
+ADAIN_API int adain_get_schedule(void);
 
 /* ---- weights: pack a reference state_dict once (net.vgg / net.decoder, net.py:6-92) ----------------
  * w[i] / b[i] are the OIHW weight and bias tensors of the i-th conv in module order
@@ -223,6 +241,15 @@ ADAIN_API int adain_conv3x3_wino4_pack(const float* w_oihw, float* packed, int c
 ADAIN_API int adain_conv3x3_wino(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,
                        int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out, int form,
                        adain_stream_t stream);
+
+/* The same layer (form 5) as ADAIN_SCHEDULE_LATENCY runs it, whatever the calling thread's schedule: split along cin when the launch
+ * has fewer tiles than compute units.  *_workspace_bytes = the partial-sum slabs that launch needs (S x n x h x w x cout floats;
+ * 0: it would not be split, and adain_conv3x3_wino4_split then is adain_conv3x3_wino).  For unit tests and the per-layer error
+ * probe (tools/probes/wino_error_gpu.py). */
+ADAIN_API size_t adain_conv3x3_wino4_split_workspace_bytes(int n, int h, int w, int cin, int cout);
+ADAIN_API int adain_conv3x3_wino4_split(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,
+                              int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out, void* workspace,
+                              size_t workspace_bytes, adain_stream_t stream);
 
 #ifdef __cplusplus
 }

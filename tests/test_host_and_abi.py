@@ -31,6 +31,28 @@ def _declared(header_name):
     return sorted(set(re.findall(r"\b(adain_[a-z0-9_]+)\s*\(", header)))
 
 
+def test_schedule_is_per_thread_state():
+    """adain_set_schedule: enqueue-time state of the calling thread (include/adain_hip.h) - returns the previous value, refuses unknown
+    values, another thread keeps the default, the context manager restores."""
+    import threading
+
+    lib = _lib_built()
+    assert rt.get_schedule() == rt.SCHEDULE_BATCH
+    assert rt.set_schedule(rt.SCHEDULE_LATENCY) == rt.SCHEDULE_BATCH and rt.get_schedule() == rt.SCHEDULE_LATENCY
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.adain_get_schedule()))
+    t.start(); t.join()
+    assert seen == [rt.SCHEDULE_BATCH]
+    assert lib.adain_set_schedule(7) == -1 and b"unknown schedule" in lib.adain_last_error()
+    assert rt.get_schedule() == rt.SCHEDULE_LATENCY
+    assert rt.set_schedule(rt.SCHEDULE_BATCH) == rt.SCHEDULE_LATENCY
+    with rt.schedule(rt.SCHEDULE_LATENCY):
+        assert rt.get_schedule() == rt.SCHEDULE_LATENCY
+    assert rt.get_schedule() == rt.SCHEDULE_BATCH
+    # without a device there is nothing to split for: the slab query is 0 and the workspaces keep their two ping-pong buffers
+    assert rt.conv3x3_wino4_split_bytes(1, 32, 57, 512, 256) == 0 or torch.cuda.is_available()
+
+
 def _exported_functions(path):
     """Names of the defined dynamic symbols of type T (code) of a shared library."""
     import subprocess
@@ -50,7 +72,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     # -fvisibility=hidden: the C ABI is ALL the code the product library exports (no C++ launchers, no helper functions)
     assert _exported_functions(rt.LIB_PATH) == declared
     assert not hasattr(lib, "adain_conv3x3") and not hasattr(lib, "adain_debug_set_conv_stamp_buffer")
-    assert lib.adain_abi_version() == rt.ABI_VERSION == 3
+    assert lib.adain_abi_version() == rt.ABI_VERSION == 4
     assert lib.adain_encoder_packed_floats() > 3_500_000 and lib.adain_decoder_packed_floats() > 3_500_000
     hc, wc = ctypes.c_int(), ctypes.c_int()
     lib.adain_encoded_size(45, 67, ctypes.byref(hc), ctypes.byref(wc))
@@ -62,7 +84,7 @@ def test_diagnostic_library_exports_both_headers(diag_lib):
     both = sorted(set(_declared("adain_hip.h")) | set(_declared("adain_hip_diag.h")))
     assert _exported_functions(diag_lib.LIB_PATH) == both
     assert sorted(set(diag_lib.SIGNATURES) | set(diag_lib.DIAG_SIGNATURES)) == both
-    assert diag_lib.is_diag() and diag_lib.lib().adain_abi_version() == 3
+    assert diag_lib.is_diag() and diag_lib.lib().adain_abi_version() == 4
 
 
 def test_product_library_ignores_the_environment(monkeypatch):
