@@ -234,6 +234,33 @@ _style_cache_on = True
 STYLE_ENCODES = [0]                   # style images encoded by adain_inference / get_style_embeddings so far (tests count it)
 
 
+_latency_schedule_on = False
+
+
+def set_latency_schedule(enabled):
+    """True: ``adain_inference`` runs its C-ABI calls under ADAIN_SCHEDULE_LATENCY (include/adain_hip.h): the 3x3 layers that one
+    small frame leaves under-filled - conv4_1, the decoder's first and fifth layer of a 256-class frame, the reference video loop's
+    size (video/utils.py:261-270) - are split along cin.  About 10 % less kernel time for one 256 x 456 frame; the files then differ
+    from the batch jobs' (and from the default's) by one LSB in a few bytes per thousand.  Default False: a frame's bytes do not
+    depend on how it was batched.  Returns the previous setting."""
+    global _latency_schedule_on
+    prev, _latency_schedule_on = _latency_schedule_on, bool(enabled)
+    return prev
+
+
+def _with_schedule(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def run(*args, **kwargs):
+        if not _latency_schedule_on:
+            return fn(*args, **kwargs)
+        with rt.schedule(rt.SCHEDULE_LATENCY):
+            return fn(*args, **kwargs)
+
+    return run
+
+
 def set_style_cache(enabled):
     """False: every ``adain_inference`` call re-encodes its style through the call-by-call path, as the reference does
     (test.py:63 / :77); True (default): the style's statistics are kept across calls.  Returns the previous setting."""
@@ -417,6 +444,7 @@ def compute_stylization_strength_map(depth_map, encoder_size, offset=0.15, promi
 
 
 # ---------------------------------------------------------------------------------------------------------
+@_with_schedule
 def adain_inference(
     content_img,
     style_img,

@@ -12,17 +12,17 @@ CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libadain_hip.so")
 DIAG_LIB = os.path.join(PKG, "libadain_hip_diag.so")     # -DADAIN_DIAG: env tuning switches, stamp / timing-only kernels (tools/ only)
-# The product library holds only what its schedules launch; the direct implicit-GEMM family and the F(2x2,3x3) Winograd families
-# (rounds 1-2, A/B baselines with their own tests) are compiled into the diagnostic library only.
+# Both libraries are these sources; the diagnostic one adds -DADAIN_DIAG (environment tuning switches, stamp / timing-only variants of
+# the F(4,3) x F(2,3) kernel).  The direct implicit-GEMM and F(2x2,3x3) families of rounds 1-2 were retired in round 6 (git history).
 SOURCES = ["conv_edge.hip", "conv_wino4.hip", "stats.hip", "pixel.hip", "resample.hip", "api.hip"]
-DIAG_SOURCES = ["conv_direct.hip", "conv_wino.hip", "conv_wino3.hip"]
+DIAG_SOURCES = []
 # -fvisibility=hidden: the shared library exports the C ABI of include/adain_hip.h (ADAIN_API) and nothing else
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # The MFMA kernels carry their fp32 vector-ALU work (input transform, epilogues) next to the matrix instructions, where
 # v_pk_add_f32 / v_pk_fma_f32 issue far slower than the plain forms (MI355X_MICROARCH.md, "price of one filler beside
 # MFMAs"): keep hipcc from packing f32 pairs in those files.  Measured on the Winograd kernel: +7 %.
 NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-EXTRA_FLAGS = {"conv_wino.hip": NO_PACKED_F32, "conv_wino3.hip": NO_PACKED_F32, "conv_wino4.hip": NO_PACKED_F32}
+EXTRA_FLAGS = {"conv_wino4.hip": NO_PACKED_F32}
 
 
 def _hipcc():
@@ -40,8 +40,8 @@ def _newer(target, deps):
 
 
 def build(force=False, verbose=False, diag=False):
-    """Builds the product library; ``diag=True`` builds ``libadain_hip_diag.so`` instead (the same sources with -DADAIN_DIAG plus the
-    older kernel families: environment tuning switches, stamp / timing-only variants used by tools/).  A process loads it explicitly
+    """Builds the product library; ``diag=True`` builds ``libadain_hip_diag.so`` instead (the same sources with -DADAIN_DIAG:
+    environment tuning switches, stamp / timing-only variants used by tools/).  A process loads it explicitly
     with ``runtime.use_library(runtime.DIAG_LIB_PATH)`` - nothing in the environment selects it."""
     objdir = os.path.join(PKG, "build_diag" if diag else "build")
     os.makedirs(objdir, exist_ok=True)

@@ -38,26 +38,10 @@ static const Layer DEC[8] = {{512, 256, SRC_DIRECT, 0}, {256, 256, SRC_UP2X, 0},
 static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
 constexpr size_t FIRST_W = 2 * 14 * 64, FIRST_B = 64, LAST_W = 8 * 64 * 4, LAST_B = 3;
 
-// Which form of the generic 3x3 layers the encoder / decoder schedules run.  The product library always runs - and only
-// contains - the Winograd F(4,3) x F(2,3) kernels (FORM_WINO4); the diagnostic build (-DADAIN_DIAG) also holds the direct
-// implicit GEMM and the F(2x2,3x3) kernels and can select them for A/B runs: ADAIN_WINOGRAD=0 -> direct,
-// ADAIN_WINO_MH=34 / 3 / 4 / 1 / 2 -> F(2x2,3x3) (bit-different, equally valid results).
-enum { FORM_DIRECT = 0, FORM_WINO2 = 1, FORM_WINO4 = 2 };
-#ifdef ADAIN_DIAG
-static int wino_mh() {
-    // 5 (default): F(4,3) x F(2,3); F(2x2,3x3) forms: 34 = persistent form (4) where the K loop is short (cin <= 64) and
-    // register-resident-A form (3) elsewhere; 1, 2: LDS V image forms
-    static const int mh = tune_env("ADAIN_WINO_MH", 5);
-    return mh;
-}
-static int conv_form() {
-    static const int form = tune_env("ADAIN_WINOGRAD", 1) == 0 ? FORM_DIRECT : (wino_mh() == 5 ? FORM_WINO4 : FORM_WINO2);
-    return form;
-}
-#else
-static constexpr int conv_form() { return FORM_WINO4; }
-#endif
-static size_t form_floats(int cin, int cout) { return (size_t)cin * cout * (conv_form() == FORM_WINO4 ? 24 : conv_form() == FORM_WINO2 ? 16 : 9); }
+// The generic 3x3 layers run - and the library only contains - the Winograd F(4,3) x F(2,3) kernels (csrc/conv_wino4.hip).  The direct
+// implicit GEMM and the F(2x2,3x3) families of rounds 1-2 were A/B baselines in the diagnostic build until round 6 and are retired
+// (git history; docs/HISTORY.md has their numbers).
+static size_t form_floats(int cin, int cout) { return (size_t)cin * cout * 24; }
 
 // packed layout: [first w][first b] then per generic layer [w in the form the schedules launch][b], every block 256-B
 // aligned: 75 MB for the two networks in the F(4,3) x F(2,3) form (only that form is packed and kept).
@@ -94,25 +78,11 @@ static Offsets dec_offsets() {
     return f;
 }
 
-static int pack_layer(const float* w, float* dst, int cin, int cout, hipStream_t s) {
-#ifdef ADAIN_DIAG
-    if (conv_form() == FORM_WINO2) return launch_pack_wino(w, dst, cin, cout, s);
-    if (conv_form() == FORM_DIRECT) return launch_pack_conv3x3(w, dst, cin, cout, s);
-#endif
-    return launch_pack_wino4(w, dst, cin, cout, s);
-}
+static int pack_layer(const float* w, float* dst, int cin, int cout, hipStream_t s) { return launch_pack_wino4(w, dst, cin, cout, s); }
 
 static int launch_layer(ConvArgs& a, const float* packed, const Offsets& f, int i, int src, hipStream_t s, SplitWs split = SplitWs{nullptr, 0}) {
     a.bias = packed + f.b[i];
     a.wpk = packed + f.w[i];
-#ifdef ADAIN_DIAG
-    if (conv_form() == FORM_WINO2) {
-        int mh = wino_mh();
-        if (mh == 34) mh = a.cin <= 64 ? 4 : 3;      // persistent form where the K loop is short (tools/tune_conv.py)
-        return launch_conv3x3_wino(a, src, mh, s);
-    }
-    if (conv_form() == FORM_DIRECT) return launch_conv3x3(a, src, -1, s);
-#endif
     return launch_conv3x3_wino4(a, src, s, split);
 }
 
@@ -373,9 +343,8 @@ static int encode_impl(int count, const void* const* images, int u8, float* cons
     int ch[MAX_CONV_SEGS], cw[MAX_CONV_SEGS];
     float* base = (float*)workspace;
     record(ev, 0, s);
-    const bool wino4 = conv_form() == FORM_WINO4;
     // a batch of large frames (one tensor pair, no per-layer events wanted): its big layers frame by frame, see above
-    int frame_major = (count == 1 && wino4 && !ev) ? enc_frame_major_layers(n[0], h[0], w[0]) : 0;
+    int frame_major = (count == 1 && !ev) ? enc_frame_major_layers(n[0], h[0], w[0]) : 0;
     if (frame_major && !enc_frame_major_is_safe(n[0], h[0], w[0], frame_major)) frame_major = 0;
     for (int i = 0; i < count; ++i) {
         bufA[i] = base;
@@ -402,18 +371,10 @@ static int encode_impl(int count, const void* const* images, int u8, float* cons
             float* out = (l == 7) ? feats[i] : (cur[i] == bufA[i] ? bufB[i] : bufA[i]);
             segs[i] = ConvSeg{cur[i], out, n[i], ch[i], cw[i], ch[i], cw[i], 0, 0, 0};
         }
-        if (wino4) {
-            // one launch for every batch: the persistent kernel's tile list runs over all of them (csrc/conv_wino4.hip, SEGMENTS)
-            a.bias = packed + f.b[l];
-            a.wpk = packed + f.w[l];
-            RET_IF(launch_conv3x3_wino4_multi(a, segs, count, ENC[l].src, s, split));
-        } else {
-            for (int i = 0; i < count; ++i) {
-                a.in = segs[i].in; a.out = segs[i].out; a.n = n[i];
-                a.Hs = a.H = ch[i]; a.Ws = a.W = cw[i];
-                RET_IF(launch_layer(a, packed, f, l, ENC[l].src, s));
-            }
-        }
+        // one launch for every batch: the persistent kernel's tile list runs over all of them (csrc/conv_wino4.hip, SEGMENTS)
+        a.bias = packed + f.b[l];
+        a.wpk = packed + f.w[l];
+        RET_IF(launch_conv3x3_wino4_multi(a, segs, count, ENC[l].src, s, split));
         record(ev, l + 2, s);
         for (int i = 0; i < count; ++i) {
             cur[i] = segs[i].out;
@@ -470,7 +431,7 @@ int adain_decode(const float* feat, float* image, const float* packed, void* wor
     record(ev, 0, s);
     // a batch of large frames: the leading small layers over the whole batch, then everything from the first big layer to the
     // image frame by frame (see enc_frame_major_layers)
-    int batched = (conv_form() == FORM_WINO4 && !ev) ? dec_batched_layers(n, hc, wc) : 8;
+    int batched = !ev ? dec_batched_layers(n, hc, wc) : 8;
     if (!dec_frame_major_is_safe(n, hc, wc, batched)) batched = 8;
     for (int i = 0; i < batched; ++i) {
         ConvArgs a{};
@@ -736,17 +697,12 @@ int adain_conv3x3_wino(const float* in, float* out, const float* packed_w, const
     ConvArgs a{};
     a.in = in; a.out = out; a.wpk = packed_w; a.bias = bias;
     a.n = n; a.H = h; a.W = w; a.Hs = hs; a.Ws = ws; a.cin = cin; a.cout = cout; a.relu = relu; a.pool_out = pool_out ? 1 : 0;
-    if (mh == 5) {      // F(4,3) x F(2,3): weights packed by adain_conv3x3_wino4_pack
-        a.dbg = g_conv_dbg;     // diagnostic builds only (tools/wino4_probe.py sets it)
-        return launch_conv3x3_wino4(a, src_mode, (hipStream_t)stream);
+    if (mh != 5) {      // F(4,3) x F(2,3), weights packed by adain_conv3x3_wino4_pack: the one form this library holds
+        set_error("conv3x3_wino: form %d is retired (rounds 1-2: F(2x2,3x3) forms 1-4); this library runs form 5, F(4,3) x F(2,3)", mh);
+        return ADAIN_EINVAL;
     }
-#ifdef ADAIN_DIAG
-    a.dbg = (mh >= 13 && mh <= 17) ? g_conv_dbg : nullptr;
-    return launch_conv3x3_wino(a, src_mode, mh, (hipStream_t)stream);
-#else
-    set_error("conv3x3_wino: form %d exists in the diagnostic library only (this library runs form 5, F(4,3) x F(2,3))", mh);
-    return ADAIN_EINVAL;
-#endif
+    a.dbg = g_conv_dbg;     // diagnostic builds only (tools/wino4_probe.py sets it)
+    return launch_conv3x3_wino4(a, src_mode, (hipStream_t)stream);
 }
 
 size_t adain_conv3x3_wino4_split_workspace_bytes(int n, int h, int w, int cin, int cout) {
@@ -766,29 +722,6 @@ int adain_conv3x3_wino4_split(const float* in, float* out, const float* packed_w
 /* ---- diagnostic library only (include/adain_hip_diag.h) -------------------------------------------------------------------- */
 int adain_debug_set_conv_stamp_buffer(void* p) { g_conv_dbg = (unsigned long long*)p; return 0; }
 
-size_t adain_conv3x3_packed_floats(int cin, int cout) { return (size_t)cin * cout * 9; }
-
-int adain_conv3x3_pack(const float* w, float* packed, int cin, int cout, adain_stream_t stream) {
-    if (!w || !packed) { set_error("conv3x3_pack: null pointer"); return ADAIN_EINVAL; }
-    return launch_pack_conv3x3(w, packed, cin, cout, (hipStream_t)stream);
-}
-
-int adain_conv3x3(const float* in, float* out, const float* packed_w, const float* bias, int n, int h, int w, int hs, int ws,
-                  int cin, int cout, int src_mode, int relu, int pool_out, int variant, adain_stream_t stream) {
-    if (!in || !out || !packed_w || !bias) { set_error("conv3x3: null pointer"); return ADAIN_EINVAL; }
-    ConvArgs a{};
-    a.dbg = (variant == 10) ? g_conv_dbg : nullptr;
-    a.in = in; a.out = out; a.wpk = packed_w; a.bias = bias;
-    a.n = n; a.H = h; a.W = w; a.Hs = hs; a.Ws = ws; a.cin = cin; a.cout = cout; a.relu = relu; a.pool_out = pool_out ? 1 : 0;
-    return launch_conv3x3(a, src_mode, variant, (hipStream_t)stream);
-}
-
-size_t adain_conv3x3_wino_packed_floats(int cin, int cout) { return (size_t)cin * cout * 16; }
-
-int adain_conv3x3_wino_pack(const float* w, float* packed, int cin, int cout, adain_stream_t stream) {
-    if (!w || !packed) { set_error("conv3x3_wino_pack: null pointer"); return ADAIN_EINVAL; }
-    return launch_pack_wino(w, packed, cin, cout, (hipStream_t)stream);
-}
 #endif
 
 }  // extern "C"

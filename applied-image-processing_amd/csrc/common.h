@@ -13,13 +13,14 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // Source-gather modes of the 3x3 convolution's input (fused into the LDS staging):
 //   DIRECT : conceptual input == source tensor
 //   UP2X   : conceptual input == nearest 2x upsample of the source   (decoder, net.py:10,23,30)
-//   POOL2  : conceptual input == MaxPool2d(2,2,ceil_mode=True) of the source (encoder, net.py:46,53,66)
+//   POOL2  : conceptual input == MaxPool2d(2,2,ceil_mode=True) of the source (encoder, net.py:46,53,66) - the schedules fuse the pool into
+//            the PRODUCER's epilogue instead (ConvArgs::pool_out); the consumer-side form went with the direct kernels (docs/HISTORY.md)
 enum SrcMode { SRC_DIRECT = 0, SRC_UP2X = 1, SRC_POOL2 = 2 };
 
 struct ConvArgs {
     const float* in;    // NHWC source  [n][Hs][Ws][cin]
     float* out;         // NHWC output  [n][H][W][cout]
-    const float* wpk;   // packed weights (pack_conv3x3_kernel layout)
+    const float* wpk;   // packed weights (pack_wino4_kernel layout)
     const float* bias;  // [cout]
     int n, H, W;        // output (== conceptual input) spatial size
     int Hs, Ws;         // source spatial size
@@ -74,15 +75,10 @@ inline int tune_env(const char* name, int dflt) {
 // thread-local error text for adain_last_error()
 void set_error(const char* fmt, ...);
 
-// launchers (conv.hip)
-int launch_pack_conv3x3(const float* w_oihw, float* packed, int cin, int cout, hipStream_t s);
+// launchers (conv_edge.hip)
 int launch_pack_conv_first(const float* w0, const float* b0, const float* w1, const float* b1, float* packed,
                            float* bias_out, hipStream_t s);
 int launch_pack_conv_last(const float* w, float* packed, hipStream_t s);
-int launch_conv3x3(const ConvArgs& a, int src_mode, int variant, hipStream_t s);   // variant < 0: automatic
-// conv_wino.hip
-int launch_pack_wino(const float* w_oihw, float* packed, int cin, int cout, hipStream_t s);
-int launch_conv3x3_wino(const ConvArgs& a, int src_mode, int mh, hipStream_t s);   // mh: kernel form (1, 2: V image in LDS; 3: register A; 4: persistent)
 // Compute units of the current device (cached per device id; 0 on failure).  Sizes the persistent kernels' grids.
 inline int device_cu_count() {
     static int cached[64] = {};
@@ -109,8 +105,6 @@ int launch_conv3x3_wino4_multi(const ConvArgs& layer, const ConvSeg* segs, int c
 // floats of slab workspace a launch of this layer over n images of H x W (conv output size) needs to be split; 0: it would not be
 size_t wino4_split_floats(int n, int H, int W, int cin, int cout);
 double wino4_rounds_per_image(int H, int W, int cout);      // persistent-grid rounds one image of a layer is worth (schedules, api.hip)
-// conv_wino3.hip
-int launch_conv3x3_wino3(const ConvArgs& a, int src_mode, hipStream_t s);
 // img: NCHW float [n][3][H][W], or (u8 != 0) HWC uint8 [n][H][W][3] converted as ToTensor does (v / 255)
 int launch_conv_first(const void* img, int u8, float* out_nhwc, const float* packed, const float* bias, int n, int H,
                       int W, hipStream_t s);

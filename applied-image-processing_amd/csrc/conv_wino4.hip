@@ -7,7 +7,7 @@
 // F(4,3) is applied along the ROWS so that neighbouring lanes' patches stay 2 pixels apart in the LDS halo image (the
 // conflict pattern of the F(2x2,3x3) kernels; 4 pixels apart would be a 4-way conflict for every 16-byte-aligned pixel stride).
 //
-// Mapping (conv3x3_wino2_kernel's, with the roles of rows and columns swapped):
+// Mapping (that of the retired F(2x2,3x3) kernels - docs/HISTORY.md - with the roles of rows and columns swapped):
 //   * block = 4 waves, tile = 32 Winograd tiles (2 tile rows x 16 tile columns = 8 x 32 output pixels) x 32 channels;
 //   * the 24 transform positions xi = (r, j) are 24 GEMMs [32 tiles x cin] x [cin x 32]; wave j owns transform COLUMN j
 //     (its 6 row positions r): 6 MFMA tiles of 32x32 = 96 accumulator registers (v_mfma_f32_32x32x2_f32, A = weights,
@@ -79,7 +79,12 @@ constexpr int W4_RBUF = 8192;                          // 2 planes + tail, round
 constexpr int W4_PEX = 4 * 4 * 32 * 32;                // [column j][a][tile][32 channels] floats = 64 KiB
 static_assert(2 * W4_RBUF <= W4_PEX, "LDS layout");
 
-// literal scalar offset only: see conv_wino3.hip (gfx950 b128 buffer-store hazard)
+// 128-bit buffer store.  The scalar offset operand is deliberately NOT exposed (always the literal 0): with an SGPR soffset LLVM
+// models no hazard between a >64-bit MUBUF store and a following VALU write of its data registers and emits none of the wait states
+// it emits for the literal form - and on gfx950, with two waves per SIMD queueing VMEM work, the store then reads data the next
+// instruction has already overwritten (seen in round 2's F(2x2,3x3) kernel: the register allocator reused the first data register of
+// one store as the address of the next; the .x lane values arrived as address bit patterns).  With the literal form the compiler
+// inserts its `s_nop 1` and the stores are exact.
 __device__ __forceinline__ void buf_store4(rsrc_t r, f32x4 v, int voff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
 }
@@ -131,7 +136,10 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
 // weight fragments replace the ring's run-off loads, so a tile starts with an LDS write + barrier + transform instead of a cold
 // HBM round trip (tools/wino4_phase_probe.py: 3.4-4.1 us of prologue per one-tile workgroup; with cin = 64 both workgroups of a
 // CU are inside their main loops only 22 % of the time).  The wave priority alternates per tile between the two halves of the
-// grid (the SIMD arbiter prefers the older wave; see conv_wino3.hip).
+// grid: the SIMD arbiter prefers the older wave - the workgroup dispatched first ran its tiles ~1.4x faster than its CU partner and
+// then sat idle at the end of the launch (static tile lists); alternating the priority per tile, in opposite phase for workgroups b
+// and b + grid / 2 (they share a CU), evens the two out (round 2's persistent F(2x2,3x3) kernel: both in their main loops 71 % -> 84 %
+// of the time).
 // SEGMENTS (persistent form only): the tile list may run over up to four (source, output) tensor pairs of different sizes
 // that share the layer's weights - the content batch and the style image of one encoder pass (reference test.py:57,63 encodes
 // both through the same vgg) - so that the deep style-branch layers, too small to fill the chip on their own, ride in the
@@ -436,7 +444,10 @@ __global__ __launch_bounds__(256, DIAG == 2 ? 1 : 2) void conv3x3_wino4_kernel(C
     }
     };
 
-    // the main loop is instantiated once per transform column (WJ compile-time): see conv_wino.hip
+    // the main loop is instantiated once per transform column (WJ a compile-time constant inside): with a run-time column the compiler
+    // turns the sign selection of the column combine into scalar branches around every group of adds, which splits the MFMA steps into
+    // many basic blocks and leaves the transform outside the matrix pipe's shadow (measured on round 1's F(2x2,3x3) kernel: 1200-1300
+    // cycles for a step with the transform against 630 without, ideal 512)
     auto main_loop = [&](auto WJC) {
         constexpr int WJ = decltype(WJC)::value;
         constexpr int cA = WJ == 0 ? 0 : 1, cB = WJ == 3 ? 3 : 2;

@@ -1,4 +1,4 @@
-// Device-side helpers shared by the convolution kernels (conv.hip, conv_wino.hip).
+// Device-side helpers shared by the convolution kernels (conv_edge.hip, conv_wino4.hip).
 #pragma once
 #include "common.h"
 

@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # The product library.  Nothing in the environment can swap it: the diagnostic build (libadain_hip_diag.so, build.py --diag) is
-# loaded only by an explicit ``use_library(DIAG_LIB_PATH)`` call (tools/_diag.py, the tests of the older kernel families).
+# loaded only by an explicit ``use_library(DIAG_LIB_PATH)`` call (tools/_diag.py).
 LIB_PATH = os.path.join(_PKG, "libadain_hip.so")
 DIAG_LIB_PATH = os.path.join(_PKG, "libadain_hip_diag.so")
 
@@ -77,11 +77,6 @@ SIGNATURES = {
 
 # entry points of include/adain_hip_diag.h: exported by the diagnostic library only
 DIAG_SIGNATURES = {
-    "adain_conv3x3_packed_floats": (_c_size_t, [_c_int, _c_int]),
-    "adain_conv3x3_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
-    "adain_conv3x3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 11 + [_c_void_p]),
-    "adain_conv3x3_wino_packed_floats": (_c_size_t, [_c_int, _c_int]),
-    "adain_conv3x3_wino_pack": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
     "adain_debug_set_conv_stamp_buffer": (_c_int, [_c_void_p]),
 }
 
@@ -120,7 +115,7 @@ def lib():
 
 def use_library(path):
     """Switches the process to another build of the library (the diagnostic build, ``DIAG_LIB_PATH``; ``LIB_PATH`` switches
-    back).  Only tools/ and the tests of the older kernel families call this: the product path always runs ``LIB_PATH``."""
+    back).  Only tools/ call this: the product path always runs ``LIB_PATH``."""
     global _lib, LIB_PATH
     with _lock:
         _lib, LIB_PATH = None, path
@@ -602,57 +597,22 @@ def nchw_to_nhwc(x):
     return out
 
 
-# --- single conv layer (tests / profiling; everything but the F(4,3) x F(2,3) form needs the diagnostic library) ---------
-def _need_diag(what):
-    if not is_diag():
-        raise AdainHipError(f"{what} exists in the diagnostic library only: runtime.use_library(runtime.DIAG_LIB_PATH) "
-                            "(build it with `python applied-image-processing_amd/build.py --diag`)")
-
-
-def conv3x3_pack(w_oihw):
-    _need_diag("adain_conv3x3_pack")
-    w = _dev(w_oihw, "weight")
-    cout, cin = w.shape[:2]
-    packed = torch.empty(lib().adain_conv3x3_packed_floats(cin, cout), dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
-        _check(lib().adain_conv3x3_pack(w.data_ptr(), packed.data_ptr(), cin, cout, _stream()), "adain_conv3x3_pack")
-    return packed
-
-
-def conv3x3(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, pool_out=False, variant=-1):
-    _need_diag("adain_conv3x3")
-    x = _dev(x_nhwc, "x")
-    n, hs, ws_, cin = x.shape
-    if src_mode == SRC_UP2X:
-        h, w = 2 * hs, 2 * ws_
-    elif src_mode == SRC_POOL2:
-        h, w = (hs + 1) // 2, (ws_ + 1) // 2
-    else:
-        h, w = hs, ws_
-    oh, ow = ((h + 1) // 2, (w + 1) // 2) if pool_out else (h, w)
-    out = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        _check(lib().adain_conv3x3(x.data_ptr(), out.data_ptr(), packed_w.data_ptr(), bias.data_ptr(), n, h, w, hs, ws_, cin, cout,
-                                   src_mode, int(relu), int(pool_out), int(variant), _stream()), "adain_conv3x3")
-    return out
-
-
-def conv3x3_wino_pack(w_oihw, form=3):
-    """Packed transformed weights for conv3x3_wino; form 5 (F(4,3) x F(2,3)) has its own layout."""
+# --- single conv layer (tests / profiling) -------------------------------------------------------------------------------------
+def conv3x3_wino_pack(w_oihw, form=5):
+    """Packed transformed weights U = G4 g G2^T for conv3x3_wino / conv3x3_wino4_split (24 floats per (cin, cout) pair)."""
     if form != 5:
-        _need_diag("adain_conv3x3_wino_pack")
+        raise AdainHipError(f"conv3x3_wino_pack: form {form} is retired; the library runs form 5, F(4,3) x F(2,3)")
     w = _dev(w_oihw, "weight")
     cout, cin = w.shape[:2]
-    sizer, packer = ((lib().adain_conv3x3_wino4_packed_floats, lib().adain_conv3x3_wino4_pack) if form == 5 else
-                     (lib().adain_conv3x3_wino_packed_floats, lib().adain_conv3x3_wino_pack))
-    packed = torch.empty(sizer(cin, cout), dtype=torch.float32, device=w.device)
+    packed = torch.empty(lib().adain_conv3x3_wino4_packed_floats(cin, cout), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
-        _check(packer(w.data_ptr(), packed.data_ptr(), cin, cout, _stream()), "adain_conv3x3_wino_pack")
+        _check(lib().adain_conv3x3_wino4_pack(w.data_ptr(), packed.data_ptr(), cin, cout, _stream()), "adain_conv3x3_wino4_pack")
     return packed
 
 
-def conv3x3_wino(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, pool_out=False, m_tiles=2):
-    """Winograd F(2x2,3x3) form of conv3x3 (weights packed by conv3x3_wino_pack)."""
+def conv3x3_wino(x_nhwc, packed_w, bias, cout, src_mode=SRC_DIRECT, relu=True, pool_out=False, m_tiles=5):
+    """One generic 3x3 layer, ReflectionPad2d(1) + Conv2d [+ ReLU] [+ fused ceil-mode pool] on NHWC, in the form the schedules run
+    (``m_tiles`` = the C ABI's `form`, 5 = F(4,3) x F(2,3); weights packed by conv3x3_wino_pack)."""
     x = _dev(x_nhwc, "x")
     n, hs, ws_, cin = x.shape
     h, w = (2 * hs, 2 * ws_) if src_mode == SRC_UP2X else (hs, ws_)

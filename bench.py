@@ -183,8 +183,8 @@ import applied_image_processing_amd.synth as synth
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0           # same guide: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable by a float4 copy)
-# The product library always runs the F(4,3) x F(2,3) kernels.  `--diag-lib` (A/B runs only; the JSON line is labelled) loads the
-# diagnostic build instead, which reads ADAIN_WINOGRAD=0 (direct implicit GEMM) / ADAIN_WINO_MH (F(2x2,3x3) forms) and the tuning switches.
+# The library runs the F(4,3) x F(2,3) kernels and nothing else.  `--diag-lib` (A/B runs only; the JSON line is labelled) loads the
+# diagnostic build instead: the same sources with the environment tuning switches (ADAIN_W4_*, ADAIN_BIG_*) and timing-only variants.
 if "--diag-lib" in sys.argv:
     sys.argv.remove("--diag-lib")
     rt.use_library(rt.DIAG_LIB_PATH)
@@ -194,13 +194,9 @@ if "--lib" in sys.argv:                  # same-box A/B against another build of
     del sys.argv[_i:_i + 2]
 _OTHER_LIB = os.path.basename(rt.LIB_PATH) if os.path.basename(rt.LIB_PATH) != "libadain_hip.so" else None
 _DIAG_LIB = "diag" in os.path.basename(rt.LIB_PATH)
-WINOGRAD = not _DIAG_LIB or os.environ.get("ADAIN_WINOGRAD", "1") != "0"
-WINO_FORM = int(os.environ.get("ADAIN_WINO_MH", "5")) if _DIAG_LIB else 5
 # multiplies the conv3x3 kernel executes on the matrix pipe per direct-convolution multiply
-EXECUTED = (24.0 / 72.0 if WINO_FORM == 5 else 16.0 / 36.0) if WINOGRAD else 1.0
-CONV_KERNEL = ("conv3x3_mfma_kernel / conv3x3_persist_kernel" if not WINOGRAD else
-               "conv3x3_wino4_kernel (Winograd F(4,3) x F(2,3))" if WINO_FORM == 5 else
-               "conv3x3_wino2_kernel + conv3x3_wino3_kernel (Winograd F(2x2,3x3))")
+EXECUTED = 24.0 / 72.0
+CONV_KERNEL = "conv3x3_wino4_kernel (Winograd F(4,3) x F(2,3))"
 WORKLOADS = {
     2: "configs[1]: {h}x{w} AdaIN forward (style_transfer_simple), batch={b} per GPU, style {hs}x{ws} re-encoded every step, alpha={alpha}",
     3: "configs[2]: {h}x{w} depth-aware AdaIN (style_transfer, proximity-map blend), batch={b} per GPU, style {hs}x{ws} re-encoded every step",
@@ -668,6 +664,9 @@ def parse_args():
     ap.add_argument("--per-call", choices=["video", "guide"], default=None,
                     help="time the reference's unchanged caller loops (one adain_inference call per frame / view, files included) instead of the "
                          "BASELINE step; --steps = calls (default 20)")
+    ap.add_argument("--schedule", choices=["batch", "latency"], default="batch",
+                    help="--per-call: `latency` runs adain_inference under ADAIN_SCHEDULE_LATENCY (cin split of the layers one small frame under-fills; "
+                         "AdaIN.test.set_latency_schedule)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="bare `--gpus N` launch: seconds after which the rank processes are stopped")
     ap.add_argument("--n1-value", type=float, default=0.0, help="--job: the 1-GPU value of the same job, to report efficiency_vs_n1")
     ap.add_argument("--weights", choices=["kaiming", "trained-like"], default="kaiming",
@@ -910,6 +909,7 @@ def main_per_call(args, ctx):
     from applied_image_processing_amd.AdaIN import test as T
 
     mode, n = args.per_call, max(4, args.steps)
+    T.set_latency_schedule(args.schedule == "latency")
     h, w = ((270, 480) if mode == "video" else (800, 800)) if not args.size else (args.size, args.size)     # the callers' own shapes
     csize = 256 if mode == "video" else 512
     root = tempfile.mkdtemp(prefix="adain_per_call_")
@@ -970,7 +970,8 @@ def main_per_call(args, ctx):
               "config": {"workload": (f"{n} calls: {h}x{w} JPEG frame files, content_size=256 -> {ch}x{cw}, use_depth=True with a proximity map per frame, "
                                       "one 933x700 style file resized to 512 (video/utils.py:341-350)" if mode == "video" else
                                       f"{n} calls: {h}x{w} PIL views, content_size=512 -> {ch}x{cw}, mask = view > 0, one 933x700 PIL style resized to 512 "
-                                      "(Style_3DGS/train.py:86-115)") + ", fp32, seeded synthetic weights", "parallelism": "single GPU, one call at a time"},
+                                      "(Style_3DGS/train.py:86-115)") + ", fp32, seeded synthetic weights", "parallelism": "single GPU, one call at a time",
+                         "schedule": args.schedule},
               "per_call": {"ms": round(dt * 1e3 / n, 3), "stages_ms": stages, "kernels_ms_by_hip_events": round(gpu_ms, 3),     # from the frame's H2D copy to the last kernel (upload, resize, ~27 launches)
                            "outside_the_stages_ms": round(dt * 1e3 / n - sum(stages.values()), 3),      # the caller's own work (PIL object / mask
                                                                                                        # construction in the loop) + bookkeeping

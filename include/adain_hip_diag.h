@@ -1,8 +1,9 @@
-/* adain_hip_diag.h — entry points that exist ONLY in the diagnostic build of the library (libadain_hip_diag.so,
- * `python applied-image-processing_amd/build.py --diag`, loaded by tools/ and by the tests of the older kernel families).  The
- * product library (libadain_hip.so) exports include/adain_hip.h and nothing else: its encoder / decoder schedules run the
- * F(4,3) x F(2,3) kernels only.  The diagnostic library exports both headers; it additionally reads tuning switches from the
- * environment (ADAIN_W4_*, ADAIN_WINOGRAD, ADAIN_WINO_MH, ...) and holds stamp / timing-only kernel variants.
+/* adain_hip_diag.h — the entry point that exists ONLY in the diagnostic build of the library (libadain_hip_diag.so,
+ * `python applied-image-processing_amd/build.py --diag`, loaded by tools/).  The product library (libadain_hip.so) exports
+ * include/adain_hip.h and nothing else.  The diagnostic library is the SAME sources compiled with -DADAIN_DIAG: it exports both
+ * headers, reads tuning switches from the environment (ADAIN_W4_*, ADAIN_BIG_*) and holds the stamp / timing-only variants of the
+ * F(4,3) x F(2,3) kernel.  The older kernel families it carried until round 6 (direct implicit GEMM, F(2x2,3x3)) are retired:
+ * git history and docs/HISTORY.md keep them.
  */
 #ifndef ADAIN_HIP_DIAG_H
 #define ADAIN_HIP_DIAG_H
@@ -12,25 +13,6 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-
-/* ---- single layers of the older kernel families (A/B baselines; rounds 1-2) -----------------------------------
- * conv3x3: ReflectionPad2d(1) + Conv2d(cin, cout, 3) [+ ReLU] on NHWC as a direct implicit GEMM, with the pool / upsample of the
- * producer fused into the input gather (src_mode) and/or the max-pool behind this layer fused into the
- * epilogue (pool_out != 0: out is [n][ceil(h/2)][ceil(w/2)][cout]).  (h, w) = conv output size before any
- * output pool; (hs, ws) = source size.  cin % 16 == 0, cout % 64 == 0.  variant < 0 selects the tile shape
- * automatically; 0..7 force one (csrc/conv_direct.hip, launch_variant; 5 and 6 are the persistent kernels). */
-ADAIN_API size_t adain_conv3x3_packed_floats(int cin, int cout);
-ADAIN_API int adain_conv3x3_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
-ADAIN_API int adain_conv3x3(const float* in_nhwc, float* out_nhwc, const float* packed_w, const float* bias, int n, int h,
-                  int w, int hs, int ws, int cin, int cout, int src_mode, int relu, int pool_out, int variant,
-                  adain_stream_t stream);
-
-/* Winograd F(2x2,3x3) forms 1-4 of adain_conv3x3_wino (4 multiplies per output; packing of 16 floats per pair; cout % 64 == 0):
- *   3: A operand transformed in registers (cin % 16 == 0), 4: its persistent form (cin >= 32), 1 / 2: transformed
- *   input staged in LDS (cin % 8 == 0), 1 or 2 32-tile M-tiles per workgroup.  In this library adain_conv3x3_wino accepts
- *   form 1..5. */
-ADAIN_API size_t adain_conv3x3_wino_packed_floats(int cin, int cout);
-ADAIN_API int adain_conv3x3_wino_pack(const float* w_oihw, float* packed, int cin, int cout, adain_stream_t stream);
 
 /* a device buffer for the stamp / timing-only kernel variants (tools/wino4_probe.py and friends); NULL clears it */
 ADAIN_API int adain_debug_set_conv_stamp_buffer(void* device_buffer);

@@ -251,7 +251,7 @@ def test_depth_provider_hook_and_cli_pixels(rt, weights, tmp_path):
 
 # ---- Winograd F(4,3) x F(2,3) where its transforms cancel: large DC inputs, zero-sum filters ------------------------------------------
 @pytest.mark.parametrize("cin,cout,hw", [(64, 64, (40, 72)), (256, 256, (24, 40)), (512, 256, (16, 24))])
-def test_winograd_large_dc_zero_sum_filters(rt, diag_lib, cin, cout, hw):
+def test_winograd_large_dc_zero_sum_filters(rt, cin, cout, hw):
     """Post-ReLU-like inputs (non-negative, mean 50, sigma 1) against filters whose nine taps sum to zero: the exact result
     is O(1) while the F(4,3) input transform (coefficients up to 5) works on values of magnitude 50 x 10.  The error bound
     asserted is the path's per-layer tolerance (2e-4 absolute + relative) scaled by nothing: it must hold as is."""
@@ -266,12 +266,9 @@ def test_winograd_large_dc_zero_sum_filters(rt, diag_lib, cin, cout, hw):
     ref = F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect"), wt.double(), b.double())
     xg = x.cuda().permute(0, 2, 3, 1).contiguous()
     errs = {}
-    for form in (5, 3):
-        packed = rt.conv3x3_wino_pack(wt.cuda(), form)
-        out = rt.conv3x3_wino(xg, packed, b.cuda(), cout, rt.SRC_DIRECT, relu=False, m_tiles=form).permute(0, 3, 1, 2).cpu().double()
-        errs[form] = float((out - ref).abs().max())
-    direct = rt.conv3x3(xg, rt.conv3x3_pack(wt.cuda()), b.cuda(), cout, rt.SRC_DIRECT, relu=False).permute(0, 3, 1, 2).cpu().double()
-    errs["direct"] = float((direct - ref).abs().max())
+    packed = rt.conv3x3_wino_pack(wt.cuda(), 5)
+    out = rt.conv3x3_wino(xg, packed, b.cuda(), cout, rt.SRC_DIRECT, relu=False, m_tiles=5).permute(0, 3, 1, 2).cpu().double()
+    errs[5] = float((out - ref).abs().max())
     cpu32 = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), wt, b).double()
     errs["torch_cpu_fp32"] = float((cpu32 - ref).abs().max())
     print(f"large-DC cin={cin}: max abs error vs fp64 (|ref| max {float(ref.abs().max()):.2f}): {errs}")

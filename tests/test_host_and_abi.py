@@ -88,15 +88,16 @@ def test_diagnostic_library_exports_both_headers(diag_lib):
 
 
 def test_product_library_ignores_the_environment(monkeypatch):
-    """ADAIN_HIP_LIB (round 2's switch) no longer redirects the product runtime; the older kernel families say where they live."""
+    """ADAIN_HIP_LIB (round 2's switch) no longer redirects the product runtime; the retired kernel families say so."""
     import importlib
 
     monkeypatch.setenv("ADAIN_HIP_LIB", "/nonexistent/libother.so")
     fresh = importlib.reload(rt)
     try:
         assert fresh.LIB_PATH.endswith("libadain_hip.so") and not fresh.is_diag()
-        with pytest.raises(fresh.AdainHipError, match="diagnostic library"):
-            fresh.conv3x3_pack(torch.zeros(64, 64, 3, 3))
+        with pytest.raises(fresh.AdainHipError, match="retired"):
+            fresh.conv3x3_wino_pack(torch.zeros(64, 64, 3, 3), 3)
+        assert not hasattr(fresh, "conv3x3_pack") and not hasattr(fresh, "conv3x3")
     finally:
         importlib.reload(rt)
 
