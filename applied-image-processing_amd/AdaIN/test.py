@@ -150,6 +150,8 @@ def device_transform_u8(img, size, crop, device, mark=None):
     if plan is None:
         return None
     (nw, nh), win = plan
+    if img.size[0] > 256 * nw or img.size[1] > 256 * nh:      # beyond the device resize's supported shrink factor: Pillow on the host
+        return None
     x = _upload_rgb(img, device, mark)
     if (nw, nh) == img.size:                    # Image.resize to the size it has is a copy
         if win is None:

@@ -92,7 +92,13 @@ constexpr int CF_OSTR = 68;      // floats per pixel of the row buffer: b128 wri
 //   * the weights are consumed before the loop (their waits used to sit at their first use INSIDE it, where in every later tile
 //     they waited for the previous tile's stores to be acknowledged).
 constexpr int CF_HBUF = 1024;    // floats per halo image slot (3 planes x 340 = 1020)
-template <bool U8>
+// CFD (diagnostic library only, ADAIN_CF_DIAG; timing-only, wrong results by construction): 1 = no global stores, 2 = no MFMAs,
+// 3 = neither (round 5's ablations, tools/probes/cf_diag_ab.sh: 75.7 / 56.7 / 63.1 / 31.0 us at 1024 x 1024).
+// DEEP (round 6, the review's last structural A/B; diagnostic library, ADAIN_CF_DEEP=1): the halo loads run TWO tiles ahead - tile t
+// starts by writing tile t+1's halo (loaded during tile t-1, long arrived) into the other LDS image and then requests tile t+2's,
+// so a load has a whole tile period to arrive instead of one matrix phase; the stores are then unconditional (rows below the image
+// get an empty descriptor) so that the compiler's wait for those loads can leave the 16 younger stores in flight.
+template <bool U8, int CFD = 0, bool DEEP = false>
 __global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restrict__ img_any,
                                                             float* __restrict__ out, const float* __restrict__ wpk,
                                                             const float* __restrict__ bias, int H, int W, int tiles_x,
@@ -133,14 +139,20 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restri
                              __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src, voff, soff + 2 * pb, 0)), 0.f};
             }
         };
+        // DEEP: the second pixel's load is issued by EVERY thread (threads without one aim past the descriptor: the hardware returns 0
+        // without touching memory) - a load under a lane mask becomes a merge with the register's old value, and for a value that is
+        // carried over the loop's back edge the compiler then loads into a scratch register and waits for it at once
+        constexpr int CF_OOB = 0x7ffffff0;
         if (interior) {
             const int soff = ((ty0 - 1) * W + tx0 - 1) * EB;
             h0 = fetch(rel0, soff);
-            if (second) h1 = fetch(rel1, soff);
+            if constexpr (DEEP) h1 = fetch(second ? rel1 : CF_OOB, soff);
+            else if (second) h1 = fetch(rel1, soff);
         } else {
             auto at = [&](int hy, int hx) { return (reflect1(ty0 + hy - 1, H) * W + reflect1(tx0 + hx - 1, W)) * EB; };
             h0 = fetch(at(hy0, hx0), 0);
-            if (second) h1 = fetch(at(hy1, hx1), 0);
+            if constexpr (DEEP) h1 = fetch(second ? at(hy1, hx1) : CF_OOB, 0);
+            else if (second) h1 = fetch(at(hy1, hx1), 0);
         }
     };
     // halo registers -> LDS image `buf` (planar [r | g | b][10][34]: the K reads walk consecutive floats)
@@ -160,6 +172,10 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restri
     int t = blockIdx.x;
     if (t >= ntiles) return;
     halo_load(t);
+    if constexpr (DEEP) {        // tile t's halo to image 0 now; the registers then carry tile t + stride's
+        halo_to_lds(smem_all);
+        if (t + (int)gridDim.x < ntiles) halo_load(t + gridDim.x);
+    }
     // this lane's 2 x 14 weights (A operand; K index e = 2 g + lh) and the LDS index of halo element e = (tap, channel) for this
     // lane's pixel column in the wave's first row: held in registers over the tile walk
     float wf[2][14];
@@ -175,7 +191,7 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restri
     for (int g = 0; g < 14; ++g)
 #pragma unroll
         for (int c = 0; c < 2; ++c) asm volatile("" ::"v"(wf[c][g]));       // arrived BEFORE the loop (see above)
-    halo_to_lds(smem_all);
+    if constexpr (!DEEP) halo_to_lds(smem_all);
     float* const st = smem_all + 2 * CF_HBUF + wave * (32 * CF_OSTR);        // this wave's row buffer
     // per-lane constants of the epilogue: where this lane's four channels of pixel li go in the row buffer, which 16 bytes of the
     // row buffer it reads back (pixel 4 k + lane / 16, quad lane % 16) and where those go in the output row
@@ -190,7 +206,13 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restri
         const int tx0 = (pt % tiles_x) * 32, ty0 = (pt / tiles_x) * 8;
         __syncthreads();                                 // halo image `par` is complete (and image 1 - par is free, see above)
         const int tn = t + gridDim.x;
-        if (tn < ntiles) halo_load(tn);                  // in flight during this tile's MFMAs
+        if constexpr (DEEP) {
+            // the registers hold tile tn's halo since the previous tile: into the free image, then the request for the tile after it
+            if (tn < ntiles) halo_to_lds(smem_all + (1 - par) * CF_HBUF);
+            if (tn + (int)gridDim.x < ntiles) halo_load(tn + gridDim.x);
+        } else {
+            if (tn < ntiles) halo_load(tn);              // in flight during this tile's MFMAs
+        }
 
         f32x16 acc[2][2];      // [channel tile][row of this wave]
 #pragma unroll
@@ -210,11 +232,15 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restri
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) acc[c][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[c][g], xf[m], acc[c][m], 0, 0, 0);
+                for (int m = 0; m < 2; ++m) {
+                    if constexpr (CFD == 2 || CFD == 3) acc[c][m][g & 15] += wf[c][g] * xf[m];      // timing-only: operands kept alive, no MFMA
+                    else acc[c][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[c][g], xf[m], acc[c][m], 0, 0, 0);
+                }
         }
         // the next tile's halo goes to the OTHER LDS image here, before this tile's stores are issued (loads and stores share one
         // in-flight counter on gfx9: consumed later, the prefetched loads would wait for every store issued in between)
-        if (tn < ntiles) halo_to_lds(smem_all + (1 - par) * CF_HBUF);
+        if constexpr (!DEEP)
+            if (tn < ntiles) halo_to_lds(smem_all + (1 - par) * CF_HBUF);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int y = ty0 + wave * 2 + m;            // wave-uniform
@@ -234,15 +260,17 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const void* __restri
                     }
                     *(f32x4*)(st_w + 32 * c + 8 * q) = v;
                 }
-            if (y < H) {
+            if (DEEP || y < H) {
                 // this output row from the tile's first pixel to the END OF THE ROW: pixels right of the image fall outside the
                 // descriptor and are dropped by the hardware; the row buffer is private to the wave and LDS operations of one wave
-                // complete in order: no barrier
-                const rsrc_t dst = make_rsrc(out + (((size_t)img * H + y) * W + tx0) * 64, (unsigned)(W - tx0) * 256u);
+                // complete in order: no barrier.  (DEEP: a row below the image gets an EMPTY descriptor instead of a branch.)
+                const bool row_ok = y < H;
+                const rsrc_t dst = make_rsrc(out + (((size_t)img * H + (row_ok ? y : 0)) * W + tx0) * 64, row_ok ? (unsigned)(W - tx0) * 256u : 0u);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const f32x4 v = *(const f32x4*)(st_r + 4 * k * CF_OSTR);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, vo + k * 1024, 0, 0);
+                    if constexpr (CFD == 1 || CFD == 3) asm volatile("" ::"v"(v));        // timing-only: no global stores
+                    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, vo + k * 1024, 0, 0);
                 }
             }
         }
@@ -399,6 +427,24 @@ int launch_conv_first(const void* img, int u8, float* out, const float* packed, 
     per_cu = wgs_env;
 #endif
     const long long grid = ntiles < per_cu * cus ? ntiles : per_cu * cus;
+#ifdef ADAIN_DIAG
+    // timing-only ablations and the two-tiles-ahead variant (tools/probes/cf_diag_ab.sh; float entry only for the ablations)
+    static const int cfd = tune_env("ADAIN_CF_DIAG", 0), deep = tune_env("ADAIN_CF_DEEP", 0);
+#define CF_LAUNCH(...) hipLaunchKernelGGL((conv_first_kernel<__VA_ARGS__>), dim3((unsigned)grid), dim3(256), 0, s, img, out, packed, bias, H, W, tx, ty, (int)ntiles)
+    if (deep) {
+        if (u8) CF_LAUNCH(true, 0, true);
+        else if (cfd == 3) CF_LAUNCH(false, 3, true);
+        else CF_LAUNCH(false, 0, true);
+        return check_launch("conv_first(deep)");
+    }
+    if (!u8 && cfd >= 1 && cfd <= 3) {
+        if (cfd == 1) CF_LAUNCH(false, 1);
+        else if (cfd == 2) CF_LAUNCH(false, 2);
+        else CF_LAUNCH(false, 3);
+        return check_launch("conv_first(diag)");
+    }
+#undef CF_LAUNCH
+#endif
     if (u8) hipLaunchKernelGGL(conv_first_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, img, out, packed, bias, H, W, tx, ty, (int)ntiles);
     else hipLaunchKernelGGL(conv_first_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, img, out, packed, bias, H, W, tx, ty, (int)ntiles);
     return check_launch("conv_first");

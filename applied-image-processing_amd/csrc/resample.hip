@@ -126,8 +126,19 @@ size_t resize_pil_workspace_bytes(int hi, int wi, int ho, int wo) {
 int launch_resize_pil_bilinear_u8(const uint8_t* in, int pixel_bytes, int n, int hi, int wi, uint8_t* out, int ho, int wo, int y0, int x0, int ch,
                                   int cw, void* workspace, size_t ws_bytes, hipStream_t s) {
     if (pixel_bytes != 3 && pixel_bytes != 4) { set_error("resize_pil_bilinear_u8: source pixels of 3 (RGB) or 4 (RGBX) bytes, got %d", pixel_bytes); return -1; }
-    if (n < 1 || hi < 1 || wi < 1 || ho < 1 || wo < 1 || hi >= (1 << 24) || wi >= (1 << 24)) { set_error("resize_pil_bilinear_u8: bad size %dx%d -> %dx%d", hi, wi, ho, wo); return -1; }
-    if (y0 < 0 || x0 < 0 || ch < 1 || cw < 1 || y0 + ch > ho || x0 + cw > wo) {
+    // every side below 2^24 (Pillow's own limit on an image side is far below; keeps wo + ho, the tap-table sizes and the crop sums in int)
+    if (n < 1 || hi < 1 || wi < 1 || ho < 1 || wo < 1 || hi >= (1 << 24) || wi >= (1 << 24) || ho >= (1 << 24) || wo >= (1 << 24)) {
+        set_error("resize_pil_bilinear_u8: bad size %dx%d -> %dx%d (every side must be in [1, 2^24))", hi, wi, ho, wo);
+        return -1;
+    }
+    // a shrink factor beyond 256 (a tap window of more than ~770 source pixels per output pixel and axis, recomputed per output pixel by
+    // this one-pass kernel) is not a resize any caller of the path makes (test.py:16-24: 512 / 256 from camera-sized images): refused
+    // rather than run for seconds
+    if ((long long)hi > 256LL * ho || (long long)wi > 256LL * wo) {
+        set_error("resize_pil_bilinear_u8: shrink factor above 256 (%dx%d -> %dx%d) is not supported", hi, wi, ho, wo);
+        return -1;
+    }
+    if (y0 < 0 || x0 < 0 || ch < 1 || cw < 1 || (long long)y0 + ch > ho || (long long)x0 + cw > wo) {
         set_error("resize_pil_bilinear_u8: crop window (%d, %d, %d x %d) outside the %d x %d result", y0, x0, ch, cw, ho, wo);
         return -1;
     }
@@ -142,6 +153,7 @@ int launch_resize_pil_bilinear_u8(const uint8_t* in, int pixel_bytes, int n, int
     p += align_ints((size_t)ho * 2);
     ay.kk = p;
     hipLaunchKernelGGL(pil_coeffs_kernel, dim3((wo + ho + 255) / 256), dim3(256), 0, s, ax, ay);
+    if (int r = check_launch("resize_pil_bilinear_u8 (tap tables)")) return r;
     const dim3 g((cw + 63) / 64, (ch + 3) / 4, n), b(64, 4);
     if (pixel_bytes == 3) hipLaunchKernelGGL(pil_resize_kernel<3>, g, b, 0, s, in, out, hi, wi, ax, ay, y0, x0, ch, cw);
     else hipLaunchKernelGGL(pil_resize_kernel<4>, g, b, 0, s, in, out, hi, wi, ax, ay, y0, x0, ch, cw);

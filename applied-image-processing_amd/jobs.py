@@ -367,6 +367,17 @@ class FrameFeeder:
                 raise item
             if item.ready is not None:
                 torch.cuda.current_stream(self.device).wait_event(item.ready)
+            if self.cuda:
+                # Device tensors made on the fetch threads (device_transform_u8's resized frames, lazily computed depth maps) belong to
+                # THEIR stream's allocator pool: once this batch drops them the block may be handed to the next fetch at once, while the
+                # consumer's kernels - on another stream whenever the caller runs the job under `torch.cuda.stream(...)` - are still
+                # queued.  Telling the allocator who reads them closes that (round-5 advisor finding).
+                cur = torch.cuda.current_stream(self.device)
+                for group in (item.content, item.depth, item.mask):
+                    if isinstance(group, list):
+                        for t in group:
+                            if isinstance(t, torch.Tensor) and t.is_cuda:
+                                t.record_stream(cur)
             if isinstance(item.content, list):                           # frames that already were device tensors
                 item.content = torch.stack(item.content)
             yield item
@@ -919,6 +930,8 @@ def run_timed_jobs(job, steps, warmup, *, barrier, group=None):
         res, info = job()
     barrier()
     dt = time.perf_counter() - t0
+    if isinstance(info, dict):
+        info["t0"], info["t1"] = t0, t0 + dt          # host clock at both ends of the timed region (bench.py's telemetry window)
     if sh.dist_on() and dist.get_world_size(group) > 1:
         t = torch.tensor([dt], dtype=torch.float64)
         if "cpu" not in sh.backend_table(group):
@@ -1020,6 +1033,7 @@ def run_timed_steps(step, steps, warmup, *, barrier, block_shape, device, mode="
     m2 = mark()
     barrier()
     dt = time.perf_counter() - t0
+    info["t0"], info["t1"] = t0, t0 + dt          # host clock (time.perf_counter) at both ends of the timed region
     info["compute_ms"] = elapsed(m0, m1) * 1e3
     info["gather_ms"] = elapsed(m1, m2) * 1e3
     info["local_s"] = dt

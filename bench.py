@@ -43,6 +43,7 @@ Rank 0 prints ONE JSON line.
                 sample of the same workload; it also yields the PSNR / relative L2 of the GPU output.
 """
 import argparse
+import glob
 import json
 import math
 import os
@@ -179,6 +180,7 @@ import applied_image_processing_amd.engine as engine_mod
 import applied_image_processing_amd.jobs as jobs
 import applied_image_processing_amd.runtime as rt
 import applied_image_processing_amd.sharding as sh
+from applied_image_processing_amd.telemetry import GpuTelemetry
 import applied_image_processing_amd.synth as synth
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)"
@@ -659,7 +661,7 @@ def parse_args():
     ap.add_argument("--gather", choices=list(jobs.GATHER_MODES), default="end",
                     help="more than one rank, per-step mode: 'end' (default) = ONE gather of every rank's frames of the K timed steps at the end "
                          "of the timed region (no transport kernel beside the compute kernels); 'overlap' = one asynchronous gather per step")
-    ap.add_argument("--sustain", type=float, default=2.0, help="single GPU, per-step mode: also run the same loop for at least this many seconds "
+    ap.add_argument("--sustain", type=float, default=6.0, help="single GPU, per-step mode: also run the same loop for at least this many seconds "
                     "after the timed region and report it as `sustained` (0 = skip)")
     ap.add_argument("--per-call", choices=["video", "guide"], default=None,
                     help="time the reference's unchanged caller loops (one adain_inference call per frame / view, files included) instead of the "
@@ -767,9 +769,10 @@ class Ctx:
             sh.gather_frames(probe, n_job, dst=0, counts=[batch] * self.world)
             self.barrier()
 
-    def finish(self):
+    def finish(self, rendezvous=True):
         if self.use_dist:
-            dist.all_reduce(torch.zeros(1))
+            if rendezvous:
+                dist.all_reduce(torch.zeros(1))
             dist.destroy_process_group()
 
 
@@ -815,7 +818,9 @@ def main_job(args, ctx):
     masks = MaskStore(frames) if cfg == 5 else None
     depths = DepthStore(frames, h, w, device) if args.depth else None
     ctx.warm_transport(world, 1)
+    telemetry = GpuTelemetry(device.index).start()
     dt, res, info = jobs.run_timed_jobs(make_job(frames, masks, depth_maps=depths), args.steps, args.warmup, barrier=ctx.barrier)
+    telemetry.window("timed_region", info["t0"], info["t1"])
     if rank == 0:
         assert res is not None and res.shape == (n_total, h, w, 3), (None if res is None else res.shape)
     first_u8 = res[:2].clone() if rank == 0 else None
@@ -827,6 +832,7 @@ def main_job(args, ctx):
         mine["launch_thread_cpu_ms_per_frame"] = round(info["host_cpu_s"] * 1e3 / (hi - lo), 4)
         mine["process_cpu_ms_per_frame"] = round(info["process_cpu_s"] * 1e3 / (hi - lo), 4)
         mine["abi_calls_per_frame"] = round(info["abi_calls"] / (hi - lo), 2)
+    mine["gpu"] = telemetry.stop()          # this rank's shader clock and package power over the timed jobs (sysfs, side thread)
     if ctx.use_dist:
         dist.all_gather_object(per_rank, mine)
     else:
@@ -849,6 +855,11 @@ def main_job(args, ctx):
                 "rank0": {k: round(float(pinfo[k]), 4) for k in ("compute_s", "gather_s", "enqueue_s", "fetch_s")}, "feeder_rank0": pinfo.get("feeder"),
                 "bit_identical_to_resident": True}
 
+    if ctx.use_dist:
+        dist.barrier()        # the ranks part here: rank 0's host-only legs (roofline frame, pixel-kernel table, CPU baseline) need nobody else
+    if rank != 0:
+        ctx.finish(rendezvous=False)
+        return
     if rank == 0:
         sec_per_job = dt / args.steps
         value = n_total * h * w / 1e6 / sec_per_job
@@ -877,7 +888,7 @@ def main_job(args, ctx):
             result["rehearsal"] = {"ranks_share_a_gpu": ctx.shared_gpu, "note": "not a multi-GPU measurement"}
         if pcie is not None:
             result["pcie_inclusive"] = pcie
-        if not args.no_secondary:              # rank 0's GPU, after the timed region (the other ranks wait in the final rendezvous)
+        if not args.no_secondary:              # rank 0's GPU, after the timed region (the other ranks have left)
             result["secondary"] += measure_pixel_kernels(device)
         if not args.no_cpu:                    # rank 0's host cores, after the timed region, at every N (north_star: "in the same run")
             step.run()
@@ -885,7 +896,7 @@ def main_job(args, ctx):
             cb, psnr, rel = cpu_baseline(step, first_u8, job_frames=[frames[k] for k in range(min(2, n_total))],
                                           job_depth=[depths[k] for k in range(min(2, n_total))] if depths is not None else None)
             if world > 1:
-                cb["sample"] += f"; measured on rank 0 after the timed region while the other {world - 1} rank(s) wait in the final host rendezvous"
+                cb["sample"] += f"; measured on rank 0 after the timed region (the other {world - 1} rank(s) have left the process group and released their GPUs)"
             result["cpu_baseline"] = cb
             result["psnr_db_vs_cpu"] = round(psnr, 2) if psnr != float("inf") else "inf"
             result["rel_l2_vs_cpu"] = float(f"{rel:.3e}")
@@ -893,7 +904,7 @@ def main_job(args, ctx):
             for i, L in enumerate(layers):
                 print(f"layer {i:2d}: {L['gflop']:8.2f} GF  {L['ms']:8.4f} ms  {L['tflops']:7.2f} TF/s", file=sys.stderr)
         emit(result)
-    ctx.finish()
+    ctx.finish(rendezvous=False)
 
 
 def main_per_call(args, ctx):
@@ -1061,22 +1072,17 @@ def main():
 
     last = [None]
     ctx.warm_transport(n_job, args.batch)
+    telemetry = GpuTelemetry(device.index).start()
     phase("setup (weights, inputs, packing, transport)")
     dt, gathered, tinfo = jobs.run_timed_steps(one_step, args.steps, args.warmup, barrier=barrier, block_shape=(args.batch, oh, ow, 3),
                                                device=device, mode=args.gather, gather=use_dist, mark=step.engine.mark,
                                                elapsed=step.engine.elapsed)
     phase("warm-up + timed steps")
+    telemetry.window("timed_region", tinfo["t0"], tinfo["t1"])
     out = last[0]
-    per_rank = [None] * world
-    mine = {"rank": rank, "compute_ms": round(tinfo["compute_ms"], 3), "gather_ms": round(tinfo["gather_ms"], 3),
-            "wall_ms": round(tinfo["local_s"] * 1e3, 3)}
-    if use_dist:
-        dist.all_gather_object(per_rank, mine)
-        if rank == 0:
-            expect = n_job * (args.steps if args.gather == "end" else 1)
-            assert gathered is not None and gathered.shape[0] == expect, (None if gathered is None else gathered.shape, expect)
-    else:
-        per_rank = [mine]
+    if use_dist and rank == 0:
+        expect = n_job * (args.steps if args.gather == "end" else 1)
+        assert gathered is not None and gathered.shape[0] == expect, (None if gathered is None else gathered.shape, expect)
     del gathered
 
     # one isolated gather of one step's frames (nothing else in flight) for the transport's own cost
@@ -1102,8 +1108,24 @@ def main():
         sdt = time.perf_counter() - s0
         sustained = {"seconds": round(sdt, 3), "steps": k_s, "value": round(n_job * h * w / 1e6 / (sdt / k_s), 3),
                      "ms_per_step": round(sdt / k_s * 1e3, 4), "unit": "Mpixels/s"}
+        telemetry.window("sustained_leg", s0, s0 + sdt)
 
     phase("isolated gather + sustained leg")
+    # every rank's line of the table: HIP-event times of its own timed region and what its GPU's clock and power were meanwhile
+    per_rank = [None] * world
+    mine = {"rank": rank, "compute_ms": round(tinfo["compute_ms"], 3), "gather_ms": round(tinfo["gather_ms"], 3),
+            "wall_ms": round(tinfo["local_s"] * 1e3, 3), "gpu": telemetry.stop()}
+    if use_dist:
+        dist.all_gather_object(per_rank, mine)
+        # The ranks part HERE: what follows on rank 0 (instrumented roofline leg, pixel-kernel table, the CPU baseline - minutes of host
+        # work) needs nobody else, and a rank left waiting in a rendezvous would hold its GPU and run into the process group's timeout
+        # (round-5 advisor finding).  Rank 0 keeps the group only to destroy it.
+        dist.barrier()
+    else:
+        per_rank = [mine]
+    if rank != 0:
+        ctx.finish(rendezvous=False)
+        return
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = n_job * h * w / 1e6 / (dt / args.steps)
@@ -1145,7 +1167,7 @@ def main():
             pdt = (time.perf_counter() - p0) / args.steps
             result["pcie_inclusive"] = {"value": round(args.batch * h * w / 1e6 / pdt, 3), "unit": "Mpixels/s",
                                         "ms_per_step": round(pdt * 1e3, 4), "what": "pinned fp32 frame H2D + forward + uint8 D2H per step"}
-        if not args.no_secondary:              # rank 0's GPU, after the timed region (the other ranks wait in the final rendezvous)
+        if not args.no_secondary:              # rank 0's GPU, after the timed region (the other ranks have left)
             result["secondary"] += measure_pixel_kernels(device)
         phase("pcie / secondary pixel kernels")
         if not args.no_cpu:                    # rank 0's host cores, after the timed region, at every N (north_star: "in the same run")
@@ -1154,7 +1176,7 @@ def main():
             cb, psnr, rel = cpu_baseline(step, step.u8 if args.config in (4, 5) else out)
             phase("cpu_baseline (the GPU idles)")
             if world > 1:
-                cb["sample"] += f"; measured on rank 0 after the timed region while the other {world - 1} rank(s) wait in the final host rendezvous"
+                cb["sample"] += f"; measured on rank 0 after the timed region (the other {world - 1} rank(s) have left the process group and released their GPUs)"
             result["cpu_baseline"] = cb
             result["psnr_db_vs_cpu"] = round(psnr, 2) if psnr != float("inf") else "inf"
             result["rel_l2_vs_cpu"] = float(f"{rel:.3e}")
@@ -1165,7 +1187,7 @@ def main():
         # baseline, so a utilisation sampler beside the whole run sees a mostly idle GPU
         result["run_phases_s"] = phases
         emit(result)
-    ctx.finish()
+    ctx.finish(rendezvous=False)          # (the other ranks left after the per-rank table)
 
 
 if __name__ == "__main__":

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """One-off shape fuzz on the GPU box: random content / style sizes and batches through style_transfer_simple / style_transfer and
-the decoder alone, against the CPU oracle (relative L2 <= 1e-4, the parity bar; 2e-4 with the trained-like weight set, see
-tests/test_gpu_trained_like.py).  Test infrastructure (it runs the oracle), not collected by pytest:
+the decoder alone, against the CPU oracle: relative L2 <= 1e-4, the parity bar of both weight sets (tests/test_gpu_trained_like.py).
+One class of input is judged otherwise AND COUNTED: a case whose fp32 oracle is itself more than 3e-5 from its float64 run (a relu4_1
+map of a dozen positions: AdaIN divides by the standard deviation of ten samples and amplifies every fp32 path's rounding) must
+stay within 4 x the oracle's own distance; the summary line names how many such cases there were, and more than 2 % of the cases
+fails the run.  Test infrastructure (it runs the oracle), not collected by pytest:
     python tests/fuzz_shapes.py [n_cases] [seed] [kaiming|trained-like]"""
 import os
 import sys
@@ -20,7 +23,9 @@ from oracle import adain_oracle as O  # noqa: E402
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 KIND = sys.argv[3] if len(sys.argv) > 3 else "kaiming"
-TOL = 1e-4 if KIND == "kaiming" else 2e-4
+TOL = 1e-4
+ILL_FLOOR, ILL_FACTOR, ILL_SHARE = 3e-5, 4.0, 0.02
+excused = []
 _v, _d = synth.state_dicts(KIND, 0)
 vgg_sd, dec_sd = synth.to_torch(_v), synth.to_torch(_d)
 net.vgg.load_state_dict(vgg_sd)
@@ -57,16 +62,16 @@ for case in range(n_cases):
     note = ""
     ok = rel <= TOL
     if not ok and mode != 2:
-        # an ill-conditioned case (a relu4_1 map of a few positions: AdaIN divides by a standard deviation of ten samples) amplifies
-        # EVERY fp32 path's rounding noise: judge the HIP path by the yardstick of tests/test_gpu_trained_like.py - no further from
-        # the float64 oracle than 5 x the fp32 oracle itself is
         v64, d64 = {k: v.double() for k, v in vgg_sd.items()}, {k: v.double() for k, v in dec_sd.items()}
         with torch.no_grad():
             tru = (O.style_transfer_simple(v64, d64, c.double(), s.double(), alpha) if mode == 0 else
                    O.style_transfer(v64, d64, c.double(), s.double(), d.double(), 1.0, 0.2, 15))
         mine, floor = float((got.double() - tru).norm() / tru.norm()), float((ref.double() - tru).norm() / tru.norm())
-        ok = mine <= 5.0 * floor
-        note = f"   (ill-conditioned: the fp32 oracle itself is {floor:.2e} from float64, the HIP path {mine:.2e} = {mine / floor:.1f} x)"
+        ok = floor > ILL_FLOOR and mine <= ILL_FACTOR * floor
+        note = f"   (the fp32 oracle itself is {floor:.2e} from float64, the HIP path {mine:.2e} = {mine / floor:.1f} x)"
+        if ok:
+            excused.append((case, rel, mine / floor))
+            note += "   ILL-CONDITIONED: judged by the float64 yardstick, counted"
     else:
         worst = max(worst, rel)
     flag = note if ok and tuple(got.shape) == tuple(ref.shape) else note + "   <-- FAIL"
@@ -74,4 +79,8 @@ for case in range(n_cases):
     flag = "" if ok and tuple(got.shape) == tuple(ref.shape) else "FAIL"
     if flag:
         sys.exit(1)
-print(f"{KIND} weights, {n_cases} cases, worst relative L2 (well-conditioned cases) {worst:.2e}, {time.time() - t0:.0f} s")
+print(f"{KIND} weights, {n_cases} cases, worst relative L2 {worst:.2e} (bar {TOL:g}); ill-conditioned cases judged by the float64 yardstick: "
+      f"{len(excused)} {[(c, float(f'{r:.3g}'), float(f'{x:.2g}')) for c, r, x in excused]}, {time.time() - t0:.0f} s")
+if len(excused) > ILL_SHARE * n_cases:
+    print("too many excused cases   <-- FAIL")
+    sys.exit(1)

@@ -341,8 +341,27 @@ def _steps_worker(rank, world, port, mode, steps, warmup, b, q):
 
         barriers = []
         sh.reset_calls()
-        dt, got, info = jobs.run_timed_steps(step, steps, warmup, barrier=lambda: (barriers.append(1), jobs.host_barrier()),
+        # bench.py's per-rank telemetry beside the loop (a stand-in hwmon directory: no GPU here): sampled on a side thread, summarised
+        # over the timed region's own host-clock window, carried in the line as per_rank[*].gpu
+        import tempfile
+
+        from applied_image_processing_amd.telemetry import GpuTelemetry
+
+        hw = tempfile.mkdtemp()
+        for name, v in (("freq1_input", (2300 + rank) * 10 ** 6), ("power1_input", 1350 * 10 ** 6), ("power1_cap", 1400 * 10 ** 6)):
+            with open(os.path.join(hw, name), "w") as f:
+                f.write(str(v))
+        tele = GpuTelemetry(0, interval=0.001, hwmon_dir=hw).start()
+        dt, got, info = jobs.run_timed_steps(step, steps, warmup, barrier=lambda: (barriers.append(1), jobs.host_barrier(), time.sleep(0.01)),
                                              block_shape=(b, 4, 6, 3), device=torch.device("cpu"), mode=mode)
+        assert info["t1"] - info["t0"] == pytest.approx(info["local_s"]) and info["t0"] > 0
+        tele.window("timed_region", info["t0"], info["t1"])
+        g = tele.stop()
+        assert g["available"] and g["power_cap_w"] == 1400.0 and g["timed_region"]["samples"] >= 1
+        assert g["timed_region"]["sclk_mhz"]["median"] == 2300 + rank and g["timed_region"]["power_w"]["median"] == 1350
+        table = [None] * world
+        dist.all_gather_object(table, {"rank": rank, "gpu": g})
+        assert [t["gpu"]["timed_region"]["sclk_mhz"]["median"] for t in table] == [2300 + r for r in range(world)]
         assert len(calls) == warmup + steps and len(barriers) == 3 and dt > 0          # one before the warm-up steps, two around the timed ones
         if mode == "end":                  # ONE gather in the timed region (and one, of the same shape, in the warm-up)
             assert sh.CALLS["gather"] == 2 and info["gathers"] == 1 and info["gather_bytes"] == steps * b * 72

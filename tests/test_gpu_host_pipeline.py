@@ -220,3 +220,38 @@ def test_jobs_random_shapes_host_feeder_vs_direct_engine_calls(rt, engine):
             want = engine.to_u8(out)[0]
             assert torch.equal(got[i], want), (case, n, h, w, sub, kind, i)
         assert info["feeder"]["batches"] >= -(-n // (sub or 32))
+
+
+def test_job_under_a_side_stream_with_frames_made_on_the_fetch_threads(rt, engine):
+    """The guide / video feeders hand over frames that the FETCH threads made on the device (device_transform_u8: the resized frame is
+    allocated under the fetching thread's stream).  Run under ``torch.cuda.stream(side)`` the consumer reads them on another stream:
+    the feeder now tells the allocator so (``record_stream``); the job must give the bytes of the default-stream run, pass after pass,
+    while later fetches keep allocating (round-5 advisor finding)."""
+    from PIL import Image
+
+    import applied_image_processing_amd.jobs as jobs
+    from applied_image_processing_amd.AdaIN.test import device_transform_u8
+
+    dev = torch.device("cuda:0")
+    pil = [Image.fromarray(u8img(900 + i, 120 + 8 * (i % 3), 200)) for i in range(24)]
+
+    class Views:                          # every fetch decodes nothing but resizes on the device: a fresh device tensor per frame
+        def __len__(self):
+            return len(pil)
+
+        def __getitem__(self, k):
+            return device_transform_u8(pil[k], 96, False, dev)[0]
+
+    style = T(synth.image(700, 1, 64, 80)).cuda()
+    stats = engine.set_style(style).style_stats()
+    want, _ = jobs.stylize_frames_sharded(engine, Views(), style, sub_batch=3, style_cache={0: stats}, gather=False, fetch_workers=3)
+    want = [w.clone() for w in want]
+    side = torch.cuda.Stream(dev)
+    for _ in range(3):
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            got, _ = jobs.stylize_frames_sharded(engine, Views(), style, sub_batch=3, style_cache={0: stats}, gather=False, fetch_workers=3)
+            side.synchronize()
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)

@@ -118,7 +118,14 @@ def test_device_transform_is_test_transform_u8(rt):
             assert got is not None and got.dtype == torch.uint8 and tuple(got.shape) == (1,) + want.shape, (h, w, size, crop)
             assert np.array_equal(got[0].cpu().numpy(), want), (h, w, size, crop)
     small = Image.fromarray(picture(7, 40, 60))
-    assert t.device_transform_u8(small, 0, True, dev) is None or True           # (size 0 with crop never occurs: CenterCrop(0))
+    # size 0 = "keep the size" (test.py:17: `if size != 0`): the uploaded bytes themselves, no resize launch
+    whole = t.device_transform_u8(small, 0, False, dev)
+    assert whole is not None and tuple(whole.shape) == (1, 40, 60, 3) and np.array_equal(whole[0].cpu().numpy(), np.asarray(small))
+    # a shrink factor beyond 256 is refused by the C ABI (with a message) and left to Pillow on the host by the transform
+    wide = Image.fromarray(picture(8, 3, 3000))
+    with pytest.raises(rt.AdainHipError, match="shrink factor"):
+        rt.resize_pil_bilinear_u8(torch.from_numpy(np.asarray(wide)).cuda()[None], (10, 3))
+    assert t.device_transform_u8(Image.fromarray(picture(9, 300, 6000)), 1, False, dev) is None          # 300 x: the host path's
     assert t.device_transform_u8(small.convert("RGBA"), 32, False, dev) is None
     assert t.device_transform_u8(small.convert("L"), 32, False, dev) is None
 

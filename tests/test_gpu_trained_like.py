@@ -21,13 +21,25 @@ from test_oracle_golden import g_inputs, rel_l2
 pytestmark = pytest.mark.gpu
 
 REPORT = {}
-# Stated tolerance in THIS regime: relative L2 <= 2e-4 against the reference's fp32 output, and no further from float64 than 5 x the
-# reference's own fp32 run is.  Measured (gpurun_out/trained_like_report.json -> profiles/r05_trained_like_parity.json): folded first
-# layer 2.5e-7 (2 x the reference's own distance from float64); relu4_1 features 1.3e-5 (2.9 x); output images 0.75 - 1.1e-4
-# (3.0 - 3.5 x; the reference itself sits 2.5e-5 from float64 there).  The factor of 3 is the fp32 accumulation over cin in the
-# Winograd domain (tools/probes/wino_error_model.py: with an exact accumulation the modelled layer error falls from 6.1e-7 to
-# 2.0e-7, the direct form's 1.6e-7; no single transform position carries it).  With the Kaiming set every number is 2-4e-6.
-TOL, FLOOR = 2e-4, 5.0
+# The bar, the same in every file that states one (README, DESIGN section 2, tests/fuzz_shapes.py, tests/verify_real_weights.py --tol):
+# relative L2 <= 1e-4 against the reference's fp32 output at EVERY stage, in both weight regimes.  This file additionally holds each
+# stage of the trained-like regime at 1.5 x what it measures today, and at a multiple of the reference's OWN fp32 rounding noise (its
+# distance from its float64 run: case_g holds both), so that a regression of an intermediate stage cannot hide under the image bound.
+# History, said plainly: round 5 first stated 1e-4 here, the first run read 1.09e-4 on `out_a10`, and the tolerance was raised to a
+# blanket 2e-4; the same round then packed U = G g G^T from double (a systematic few-ulp error per weight gone) - and nobody re-read
+# the numbers: on that binary and since, every image is at 6.9 - 8.0e-5 (gpurun_out/trained_like_report.json ->
+# profiles/r06_trained_like_parity.json).  Round 6 therefore states 1e-4 again and removes the 2e-4.
+# What is left of the factor ~2.8 over the reference's own noise is the fp32 accumulation over cin in the Winograd domain: per layer
+# 7e-7 at 64 channels per chain, 1.25e-6 at 256 (profiles/r06_wino_error_per_layer_gpu.txt: chains cut to 64 channels - the latency
+# schedule's cin split - bring every layer back to 6.5e-7).
+TOL = 1e-4
+#              rel. L2 vs reference fp32 (measured)    x the reference's own distance from float64 (measured)
+BOUNDS = {"relu1_1": (1e-6,   3.0),                 # 2.5e-7                                   2.0
+          "content_f": (2e-5, 3.5), "style_f": (2e-5, 3.5),     # 1.1 - 1.3e-5                 2.7 - 2.9
+          "mean": (5e-6, 3.5), "std": (7e-6, 3.5),              # 2.7 - 3.1e-6, 3.9 - 4.5e-6   2.4 - 2.8
+          "adain": (2e-5, 3.5),                                 # 1.3e-5                       2.5 - 2.9
+          "out_a05": (TOL, 4.0), "out_a10": (TOL, 4.0), "out_depth": (TOL, 4.0)}      # 6.9 - 8.0e-5   2.5 - 3.1
+FLOOR = 4.0          # larger frames against the oracle: 3.0 - 3.1 measured
 
 
 def T(a):
@@ -65,8 +77,10 @@ def nets_tl(weights_tl):
             json.dump(REPORT, f, indent=1, sort_keys=True)
 
 
-def check(tag, key, got, g, tol=TOL, floor_factor=FLOOR):
-    """``got`` against the reference's fp32 output (<= tol) and against its float64 run (<= floor_factor x the reference's own distance)."""
+def check(tag, key, got, g):
+    """``got`` against the reference's fp32 output (<= the stage's bound) and against its float64 run (<= the stage's multiple of the
+    reference's own distance from it)."""
+    tol, floor_factor = BOUNDS[key]
     ref, f64 = g[f"{tag}_{key}"], g[f"{tag}_{key}_f64"]
     got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
     assert got.shape == ref.shape, (got.shape, ref.shape)
@@ -88,7 +102,7 @@ def test_folded_first_layer_at_caffe_magnitudes(rt, weights_tl, tag):
     b = rt.encode_relu1_1(T(cu8[None]).cuda(), packed)
     assert torch.equal(a, b)
     got = nchw(a)
-    check(tag, "relu1_1", got, g, tol=1e-6, floor_factor=4.0)          # measured 2.5e-7: 2 x the unfolded reference's own 1.1e-7 from float64
+    check(tag, "relu1_1", got, g)          # measured 2.5e-7: 2 x the unfolded reference's own 1.1e-7 from float64
     assert float(np.abs(got - g[f"{tag}_relu1_1"]).max()) <= 1e-4 * float(np.abs(g[f"{tag}_relu1_1"]).max())
 
 
@@ -102,7 +116,7 @@ def test_whole_network_against_case_g(rt, nets_tl, tag):
     c, s, depth = c.cuda(), s.cuda(), depth.cuda()
     cf, sf = vgg(c), vgg(s)
     check(tag, "content_f", cf, g)
-    check(tag, "style_f", sf, g, floor_factor=1e9)             # (no float64 run of the style features is needed twice: fp32 check only)
+    check(tag, "style_f", sf, g)
     m, sd = fn.calc_mean_std(cf)
     check(tag, "mean", m, g)
     check(tag, "std", sd, g)
