@@ -856,7 +856,7 @@ def main_job(args, ctx):
                 "bit_identical_to_resident": True}
 
     if ctx.use_dist:
-        dist.barrier()        # the ranks part here: rank 0's host-only legs (roofline frame, pixel-kernel table, CPU baseline) need nobody else
+        dist.all_reduce(torch.zeros(1))        # the ranks part here (host rendezvous over gloo): rank 0's host-only legs (roofline frame, pixel-kernel table, CPU baseline) need nobody else
     if rank != 0:
         ctx.finish(rendezvous=False)
         return
@@ -1120,7 +1120,7 @@ def main():
         # The ranks part HERE: what follows on rank 0 (instrumented roofline leg, pixel-kernel table, the CPU baseline - minutes of host
         # work) needs nobody else, and a rank left waiting in a rendezvous would hold its GPU and run into the process group's timeout
         # (round-5 advisor finding).  Rank 0 keeps the group only to destroy it.
-        dist.barrier()
+        dist.all_reduce(torch.zeros(1))          # (host rendezvous over gloo, as Ctx.barrier does)
     else:
         per_rank = [mine]
     if rank != 0:

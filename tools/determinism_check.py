@@ -14,5 +14,16 @@ for (h, w, n) in ((1024, 1024, 1), (1080, 1920, 2), (517, 333, 3), (2048, 2048, 
         if not torch.equal(out, ref):
             bad += 1; print("MISMATCH", h, w, n, i, float((out - ref).abs().max()))
     print(h, w, n, "40 repeats identical" if not bad else "differences", flush=True)
+# round 6: the latency schedule (cin split + fixed-order combine) on single small frames - the same call must give the same bits
+import applied_image_processing_amd.runtime as rt
+with rt.schedule(rt.SCHEDULE_LATENCY):
+    for (h, w, n) in ((256, 456, 1), (128, 228, 1), (270, 480, 1), (64, 96, 2), (512, 512, 1)):
+        c = torch.from_numpy(synth.image(3, n, h, w)).cuda(); s = torch.from_numpy(synth.image(2, 1, 512, 512)).cuda()
+        ref = t.style_transfer_simple(net.vgg, net.decoder, c, s, 0.5)
+        for i in range(40):
+            out = t.style_transfer_simple(net.vgg, net.decoder, c, s, 0.5)
+            if not torch.equal(out, ref):
+                bad += 1; print("MISMATCH (latency schedule)", h, w, n, i, float((out - ref).abs().max()))
+        print(h, w, n, "latency schedule: 40 repeats identical" if not bad else "differences", flush=True)
 print("determinism:", "ok" if not bad else f"{bad} mismatches")
 sys.exit(1 if bad else 0)

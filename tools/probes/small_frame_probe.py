@@ -28,12 +28,17 @@ for (h, w, n) in ((256, 456, 256), (512, 912, 128), (1080, 1920, 32)):
         def block(self, i, j):
             return dev_frames[i:j]
 
-    for sub in (1, 2, 4, 8, 16, 32):
+    import applied_image_processing_amd.runtime as rt
+
+    for sub, sched in ((1, rt.SCHEDULE_BATCH), (1, rt.SCHEDULE_LATENCY), (2, rt.SCHEDULE_BATCH), (2, rt.SCHEDULE_LATENCY), (4, rt.SCHEDULE_BATCH),
+                       (8, rt.SCHEDULE_BATCH), (16, rt.SCHEDULE_BATCH), (32, rt.SCHEDULE_BATCH)):
         if sub > n:
             continue
         best = 1e9
-        for rep in range(3):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            jobs.stylize_frames_sharded(eng, Store(), style, sub_batch=sub, style_cache=cache, out_hw=(8 * -(-h // 8), 8 * -(-w // 8)))
-            torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-        print(f"{h}x{w} x {n} frames, sub-batch {sub:2d}: {n / best:8.1f} frames/s  {n * h * w / 1e6 / best:7.1f} Mpixels/s", flush=True)
+        with rt.schedule(sched):          # round 6: the latency schedule (cin split of under-filled layers) beside the default
+            for rep in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                jobs.stylize_frames_sharded(eng, Store(), style, sub_batch=sub, style_cache=cache, out_hw=(8 * -(-h // 8), 8 * -(-w // 8)))
+                torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        name = "latency" if sched == rt.SCHEDULE_LATENCY else "batch  "
+        print(f"{h}x{w} x {n} frames, sub-batch {sub:2d}, schedule {name}: {n / best:8.1f} frames/s  {n * h * w / 1e6 / best:7.1f} Mpixels/s", flush=True)
