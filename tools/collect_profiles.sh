@@ -21,19 +21,19 @@ run() {   # name seconds program rocprof-args...   (BENCH_ARGS = the program's a
 for part in $parts; do
   case $part in
     trace)   # config 2 WITH the secondary leg: the frame-sized pixel kernels of the post-pass are in the same trace
-      BENCH_ARGS="--no-cpu --steps 10 --warmup 2" run trace 300 bench.py --kernel-trace --stats ;;
+      BENCH_ARGS="--no-cpu --steps 10 --warmup 2 --sustain 2" run trace 300 bench.py --kernel-trace --stats ;;
     pmc)
-      BENCH_ARGS="--no-cpu --no-secondary --steps 5 --warmup 1" run fetch 300 bench.py --pmc FETCH_SIZE --kernel-trace
-      BENCH_ARGS="--no-cpu --no-secondary --steps 5 --warmup 1" run write 300 bench.py --pmc WRITE_SIZE --kernel-trace
-      BENCH_ARGS="--no-cpu --no-secondary --steps 5 --warmup 1" run sq 300 bench.py --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace ;;
+      BENCH_ARGS="--no-cpu --no-secondary --steps 5 --warmup 1 --sustain 2" run fetch 300 bench.py --pmc FETCH_SIZE --kernel-trace
+      BENCH_ARGS="--no-cpu --no-secondary --steps 5 --warmup 1 --sustain 2" run write 300 bench.py --pmc WRITE_SIZE --kernel-trace
+      BENCH_ARGS="--no-cpu --no-secondary --steps 5 --warmup 1 --sustain 2" run sq 300 bench.py --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace ;;
     configs)
       for cfg in 3 4 5; do
-        BENCH_ARGS="--config $cfg --no-cpu --no-secondary --steps 5 --warmup 1" run cfg${cfg}_trace 300 bench.py --kernel-trace --stats
+        BENCH_ARGS="--config $cfg --no-cpu --no-secondary --steps 5 --warmup 1 --sustain 2" run cfg${cfg}_trace 300 bench.py --kernel-trace --stats
       done ;;
     waits)   # wave-state and L2 hit/miss counters of configs 2 and 3 (is the larger map's extra L2-miss traffic free?)
       for cfg in 2 3; do
-        BENCH_ARGS="--config $cfg --no-cpu --no-secondary --steps 3 --warmup 1" run cfg${cfg}_waits 300 bench.py --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace
-        BENCH_ARGS="--config $cfg --no-cpu --no-secondary --steps 3 --warmup 1" run cfg${cfg}_tcc 300 bench.py --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace
+        BENCH_ARGS="--config $cfg --no-cpu --no-secondary --steps 3 --warmup 1 --sustain 2" run cfg${cfg}_waits 300 bench.py --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace
+        BENCH_ARGS="--config $cfg --no-cpu --no-secondary --steps 3 --warmup 1 --sustain 2" run cfg${cfg}_tcc 300 bench.py --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace
       done ;;
     all_kernels)
       BENCH_ARGS="" run all_kernels 300 tools/all_kernels.py --kernel-trace --stats ;;

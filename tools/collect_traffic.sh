@@ -14,7 +14,7 @@ for item in "$@"; do
     name="cfg${cfg}${suffix}_$( [ $ctr = FETCH_SIZE ] && echo fetch || echo write )"
     echo "=== $name"
     timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/prof_${tag}_$name" -- python3 "$root/bench.py" --config "$cfg" \
-        --batch "$batch" --no-cpu --no-secondary --steps 5 --warmup 1 > "$out/prof_${tag}_$name.log" 2> "$out/prof_${tag}_$name.err"
+        --batch "$batch" --no-cpu --no-secondary --steps 5 --warmup 1 --sustain 2 > "$out/prof_${tag}_$name.log" 2> "$out/prof_${tag}_$name.err"
     rc=$?; echo "=== $name rc=$rc"
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timed out: stopping"; exit 1; fi
   done

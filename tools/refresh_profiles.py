@@ -59,7 +59,7 @@ def counters(d):
 lines = {"c2": "config2", "c2_pcie": "config2_pcie", "c3": "config3", "c4": "config4", "c5": "config5", "c4job": "config4_job",
          "c5job": "config5_job", "c2_ws1": "config2_ws1_rccl", "c4job_ws1": "config4_job_ws1_rccl", "c5job_ws1": "config5_job_ws1_rccl",
          "c2_ws1_overlap": "config2_ws1_rccl_gather_overlap", "c2_style1024": "config2_style1024", "c4_depth_job": "config4_depth_job",
-         "c2_tl": "config2_trained_like", "c4job_tl": "config4_job_trained_like", "pc_video": "per_call_video", "pc_guide": "per_call_guide", "reh2_end": "rehearsal_2ranks_one_gpu", "reh3_job": "rehearsal_3ranks_one_gpu_job5_chunked"}
+         "c2_tl": "config2_trained_like", "c4job_tl": "config4_job_trained_like", "pc_video": "per_call_video", "pc_video_lat": "per_call_video_latency", "pc_guide": "per_call_guide", "reh2_end": "rehearsal_2ranks_one_gpu", "reh3_job": "rehearsal_3ranks_one_gpu_job5_chunked"}
 bench = {}
 for src, dst in lines.items():
     path = os.path.join(G, f"{btag}_{src}.log")
