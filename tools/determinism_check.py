@@ -18,7 +18,7 @@ for (h, w, n) in ((1024, 1024, 1), (1080, 1920, 2), (517, 333, 3), (2048, 2048, 
 import applied_image_processing_amd.runtime as rt
 with rt.schedule(rt.SCHEDULE_LATENCY):
     for (h, w, n) in ((256, 456, 1), (128, 228, 1), (270, 480, 1), (64, 96, 2), (512, 512, 1)):
-        c = torch.from_numpy(synth.image(3, n, h, w)).cuda(); s = torch.from_numpy(synth.image(2, 1, 512, 512)).cuda()
+        c = torch.from_numpy(synth.image(3, n, h, w)).cuda(); s = torch.from_numpy(synth.image(2, n, 512, 512)).cuda()
         ref = t.style_transfer_simple(net.vgg, net.decoder, c, s, 0.5)
         for i in range(40):
             out = t.style_transfer_simple(net.vgg, net.decoder, c, s, 0.5)
