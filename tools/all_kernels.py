@@ -95,6 +95,12 @@ called += ["adain_resize_pil_bilinear_u8", "adain_encode_relu1_1", "adain_styliz
 x = T(synth.uniform_sym(20, (1, 64, 64, 64), 1.0)).to(dev)
 w = T(synth.uniform_sym(21, (64, 64, 3, 3), 0.1)).to(dev)
 y = rt.conv3x3_wino(x, rt.conv3x3_wino_pack(w, 5), torch.zeros(64, device=dev), 64, rt.SRC_UP2X, True, False, 5)
+# round 6: the latency schedule on one small frame (cin-split one-tile launches + splitk_combine_kernel) and the split layer alone
+with rt.schedule(rt.SCHEDULE_LATENCY):
+    eng.stylize_u8(u8(24, 1, 256, 456), 0.5)
+xs = T(synth.uniform_sym(25, (1, 32, 57, 512), 1.0)).to(dev)
+ws = T(synth.uniform_sym(26, (256, 512, 3, 3), 0.02)).to(dev)
+ys = rt.conv3x3_wino4_split(xs, rt.conv3x3_wino_pack(ws, 5), torch.zeros(256, device=dev), 256, rt.SRC_DIRECT, True, True)       # with the fused pool
 torch.cuda.synchronize()
-called += ["adain_conv3x3_wino4_pack", "adain_conv3x3_wino"]
+called += ["adain_conv3x3_wino4_pack", "adain_conv3x3_wino", "adain_set_schedule", "adain_conv3x3_wino4_split"]
 print("entry points called:", ", ".join(sorted(set(called))))
