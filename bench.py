@@ -769,10 +769,26 @@ class Ctx:
             sh.gather_frames(probe, n_job, dst=0, counts=[batch] * self.world)
             self.barrier()
 
-    def finish(self, rendezvous=True):
+    # How a multi-rank run ENDS.  After the per-rank table rank 0 still has host-only legs to run (the instrumented roofline frame, the
+    # pixel-kernel table, the CPU baseline: 15 s and more) that need nobody else.  The other ranks must neither sit in a collective
+    # meanwhile (its timeout is not ours to know: round-5 advisor finding) nor tear their communicators down while rank 0 still holds
+    # its own (RCCL with N > 1 has never run here: no untested shutdown orders).  So they release their GPU memory and wait on a KEY of
+    # the rendezvous store with an explicit, generous timeout; rank 0 sets it when its line is out; then every rank destroys the group.
+    DONE_KEY = "adain_bench_rank0_done"
+
+    def others_wait_for_rank0(self, timeout_s):
+        """Ranks != 0, once their part of the measurement is over: free the device memory, then block on the store key (not a collective)."""
+        import datetime
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        dist.distributed_c10d._get_default_store().wait([self.DONE_KEY], datetime.timedelta(seconds=max(60.0, float(timeout_s))))
+
+    def finish(self, rank0_done=False):
         if self.use_dist:
-            if rendezvous:
-                dist.all_reduce(torch.zeros(1))
+            if rank0_done and self.rank == 0:
+                dist.distributed_c10d._get_default_store().set(self.DONE_KEY, b"1")
             dist.destroy_process_group()
 
 
@@ -855,10 +871,9 @@ def main_job(args, ctx):
                 "rank0": {k: round(float(pinfo[k]), 4) for k in ("compute_s", "gather_s", "enqueue_s", "fetch_s")}, "feeder_rank0": pinfo.get("feeder"),
                 "bit_identical_to_resident": True}
 
-    if ctx.use_dist:
-        dist.all_reduce(torch.zeros(1))        # the ranks part here (host rendezvous over gloo): rank 0's host-only legs (roofline frame, pixel-kernel table, CPU baseline) need nobody else
-    if rank != 0:
-        ctx.finish(rendezvous=False)
+    if rank != 0:          # rank 0's host-only legs (roofline frame, pixel-kernel table, CPU baseline) need nobody else: see Ctx.finish
+        ctx.others_wait_for_rank0(args.launch_timeout)
+        ctx.finish()
         return
     if rank == 0:
         sec_per_job = dt / args.steps
@@ -888,7 +903,7 @@ def main_job(args, ctx):
             result["rehearsal"] = {"ranks_share_a_gpu": ctx.shared_gpu, "note": "not a multi-GPU measurement"}
         if pcie is not None:
             result["pcie_inclusive"] = pcie
-        if not args.no_secondary:              # rank 0's GPU, after the timed region (the other ranks have left)
+        if not args.no_secondary:              # rank 0's GPU, after the timed region (the other ranks wait on the store key)
             result["secondary"] += measure_pixel_kernels(device)
         if not args.no_cpu:                    # rank 0's host cores, after the timed region, at every N (north_star: "in the same run")
             step.run()
@@ -896,7 +911,7 @@ def main_job(args, ctx):
             cb, psnr, rel = cpu_baseline(step, first_u8, job_frames=[frames[k] for k in range(min(2, n_total))],
                                           job_depth=[depths[k] for k in range(min(2, n_total))] if depths is not None else None)
             if world > 1:
-                cb["sample"] += f"; measured on rank 0 after the timed region (the other {world - 1} rank(s) have left the process group and released their GPUs)"
+                cb["sample"] += f"; measured on rank 0 after the timed region (the other {world - 1} rank(s) have freed their device memory and wait on a key of the rendezvous store, in no collective)"
             result["cpu_baseline"] = cb
             result["psnr_db_vs_cpu"] = round(psnr, 2) if psnr != float("inf") else "inf"
             result["rel_l2_vs_cpu"] = float(f"{rel:.3e}")
@@ -904,7 +919,7 @@ def main_job(args, ctx):
             for i, L in enumerate(layers):
                 print(f"layer {i:2d}: {L['gflop']:8.2f} GF  {L['ms']:8.4f} ms  {L['tflops']:7.2f} TF/s", file=sys.stderr)
         emit(result)
-    ctx.finish(rendezvous=False)
+    ctx.finish(rank0_done=True)
 
 
 def main_per_call(args, ctx):
@@ -1117,14 +1132,14 @@ def main():
             "wall_ms": round(tinfo["local_s"] * 1e3, 3), "gpu": telemetry.stop()}
     if use_dist:
         dist.all_gather_object(per_rank, mine)
-        # The ranks part HERE: what follows on rank 0 (instrumented roofline leg, pixel-kernel table, the CPU baseline - minutes of host
-        # work) needs nobody else, and a rank left waiting in a rendezvous would hold its GPU and run into the process group's timeout
-        # (round-5 advisor finding).  Rank 0 keeps the group only to destroy it.
-        dist.all_reduce(torch.zeros(1))          # (host rendezvous over gloo, as Ctx.barrier does)
     else:
         per_rank = [mine]
     if rank != 0:
-        ctx.finish(rendezvous=False)
+        # what follows on rank 0 (instrumented roofline leg, pixel-kernel table, the CPU baseline) needs nobody else: the other ranks
+        # free their memory and wait on a store key, not in a collective (Ctx.finish)
+        del step, last, out
+        ctx.others_wait_for_rank0(args.launch_timeout)
+        ctx.finish()
         return
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -1167,7 +1182,7 @@ def main():
             pdt = (time.perf_counter() - p0) / args.steps
             result["pcie_inclusive"] = {"value": round(args.batch * h * w / 1e6 / pdt, 3), "unit": "Mpixels/s",
                                         "ms_per_step": round(pdt * 1e3, 4), "what": "pinned fp32 frame H2D + forward + uint8 D2H per step"}
-        if not args.no_secondary:              # rank 0's GPU, after the timed region (the other ranks have left)
+        if not args.no_secondary:              # rank 0's GPU, after the timed region (the other ranks wait on the store key)
             result["secondary"] += measure_pixel_kernels(device)
         phase("pcie / secondary pixel kernels")
         if not args.no_cpu:                    # rank 0's host cores, after the timed region, at every N (north_star: "in the same run")
@@ -1176,7 +1191,7 @@ def main():
             cb, psnr, rel = cpu_baseline(step, step.u8 if args.config in (4, 5) else out)
             phase("cpu_baseline (the GPU idles)")
             if world > 1:
-                cb["sample"] += f"; measured on rank 0 after the timed region (the other {world - 1} rank(s) have left the process group and released their GPUs)"
+                cb["sample"] += f"; measured on rank 0 after the timed region (the other {world - 1} rank(s) have freed their device memory and wait on a key of the rendezvous store, in no collective)"
             result["cpu_baseline"] = cb
             result["psnr_db_vs_cpu"] = round(psnr, 2) if psnr != float("inf") else "inf"
             result["rel_l2_vs_cpu"] = float(f"{rel:.3e}")
@@ -1187,7 +1202,7 @@ def main():
         # baseline, so a utilisation sampler beside the whole run sees a mostly idle GPU
         result["run_phases_s"] = phases
         emit(result)
-    ctx.finish(rendezvous=False)          # (the other ranks left after the per-rank table)
+    ctx.finish(rank0_done=True)           # (the other ranks wait on the store key since the per-rank table)
 
 
 if __name__ == "__main__":
