@@ -291,8 +291,13 @@ def test_bench_front_door_starts_its_own_ranks():
     assert d["ranks"]["launcher"] == "bench.py self-launch" and len({x["pid"] for x in d["ranks"]["devices"]}) == 2
     assert [p["rank"] for p in d["per_rank"]] == [0, 1] and all(p["compute_ms"] > 0 for p in d["per_rank"])
     for p in d["per_rank"]:            # round 6: each rank's own GPU clock and power over its timed region (sysfs, side thread)
-        assert p["gpu"]["available"] and p["gpu"]["power_cap_w"] > 100 and p["gpu"]["timed_region"]["samples"] >= 1, p["gpu"]
-        assert 100 <= p["gpu"]["timed_region"]["sclk_mhz"]["median"] <= 3000 and p["gpu"]["timed_region"]["power_w"]["median"] > 50
+        g = p["gpu"]
+        if not g["available"]:         # a box that hides the GPU's hwmon node from the container: the line must say why, nothing else breaks
+            assert g["why"], g
+            continue
+        assert g["power_cap_w"] is None or g["power_cap_w"] > 100, g
+        assert g["timed_region"]["samples"] >= 1 and 100 <= g["timed_region"]["sclk_mhz"]["median"] <= 3000, g
+        assert g["timed_region"]["power_w"]["median"] > 50, g
     if __import__("torch").cuda.device_count() < 2:
         r = _bench(["--gpus", "2", "--no-cpu", "--steps", "3"], timeout=120)
         assert r.returncode != 0 and "2 ranks, one per GPU" in (r.stderr + r.stdout)
