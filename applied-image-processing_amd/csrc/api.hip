@@ -415,9 +415,11 @@ size_t adain_decode_workspace_bytes(int n, int hc, int wc) {
     return (align64((size_t)n * hc * wc * 1024) + align64((size_t)n * hc * wc * 4096) + dec_slab_floats(n, hc, wc)) * sizeof(float);
 }
 
-int adain_decode(const float* feat, float* image, const float* packed, void* workspace, size_t ws_bytes, int n, int hc,
-                 int wc, void* const* ev, adain_stream_t stream) {
-    if (!feat || !image || !packed || !workspace) { set_error("decode: null pointer"); return ADAIN_EINVAL; }
+// image_u8 != nullptr: the last layer writes save_image's uint8 HWC frames itself (adain_stylize_u8 without a mask: the bytes of
+// adain_decode + adain_quantize_u8, one launch and the float image's round trip through HBM less); image is then unused
+static int decode_impl(const float* feat, float* image, uint8_t* image_u8, const float* packed, void* workspace, size_t ws_bytes, int n, int hc,
+                       int wc, void* const* ev, adain_stream_t stream) {
+    if (!feat || (!image && !image_u8) || !packed || !workspace) { set_error("decode: null pointer"); return ADAIN_EINVAL; }
     if (n < 1 || hc < 2 || wc < 2) { set_error("decode: feature map %dx%d too small (needs >= 2x2)", hc, wc); return ADAIN_EINVAL; }
     if (ws_bytes < adain_decode_workspace_bytes(n, hc, wc)) { set_error("decode: workspace too small"); return ADAIN_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
@@ -448,7 +450,7 @@ int adain_decode(const float* feat, float* image, const float* packed, void* wor
         cur = a.out;
     }
     if (batched == 8) {
-        RET_IF(launch_conv_last(cur, image, packed + f.last_w, packed + f.last_b, n, ch, cw, s));
+        RET_IF(launch_conv_last(cur, image, packed + f.last_w, packed + f.last_b, n, ch, cw, s, image_u8));
         record(ev, 9, s);
         return 0;
     }
@@ -470,9 +472,16 @@ int adain_decode(const float* feat, float* image, const float* packed, void* wor
             RET_IF(launch_conv3x3_wino4(a, DEC[i].src, s));
             c = out;
         }
-        RET_IF(launch_conv_last(c + (size_t)img * ch * cw * 64, image + (size_t)img * 3 * ch * cw, packed + f.last_w, packed + f.last_b, 1, ch, cw, s));
+        RET_IF(launch_conv_last(c + (size_t)img * ch * cw * 64, image ? image + (size_t)img * 3 * ch * cw : nullptr, packed + f.last_w, packed + f.last_b,
+                                1, ch, cw, s, image_u8 ? image_u8 + (size_t)img * 3 * ch * cw : nullptr));
     }
     return 0;
+}
+
+int adain_decode(const float* feat, float* image, const float* packed, void* workspace, size_t ws_bytes, int n, int hc,
+                 int wc, void* const* ev, adain_stream_t stream) {
+    if (!image) { set_error("decode: null pointer"); return ADAIN_EINVAL; }
+    return decode_impl(feat, image, nullptr, packed, workspace, ws_bytes, n, hc, wc, ev, stream);
 }
 
 size_t adain_mean_std_workspace_bytes(int nhwc, int n, int c, int hw) { return mean_std_workspace_bytes(nhwc, n, c, hw); }
@@ -656,8 +665,10 @@ int adain_stylize_u8(const uint8_t* frames, int n, int h, int w, const float* en
     } else {                // AdaIN * alpha + content_f * (1 - alpha) (test.py:79-80)
         RET_IF(launch_adain_blend_ex(f, 1, n, 512, hw_c, c_mean, c_std, s_mean, s_std, 1, alpha, one_minus_alpha, nullptr, 1, g, s));
     }
+    if (mask_n == 0 && ((uintptr_t)out_u8 & 3) == 0)        // decoder with save_image's quantiser inside its last layer (test.py:71 / :81, :243-244): the finished uint8 frames
+        return decode_impl(g, nullptr, out_u8, dec_packed, conv, p.conv * sizeof(float), n, p.hc, p.wc, nullptr, stream);
     RET_IF(adain_decode(g, img, dec_packed, conv, p.conv * sizeof(float), n, p.hc, p.wc, nullptr, stream));     // test.py:71 / :81
-    if (mask_n == 0) return launch_quantize_u8(img, out_u8, n, 3, p.H8, p.W8, s);                                // test.py:243-244
+    if (mask_n == 0) return launch_quantize_u8(img, out_u8, n, 3, p.H8, p.W8, s);                                // test.py:243-244 (unaligned output)
     if (p.identity)         // both F.interpolate calls of test.py:227-234 are identities: composite + quantise in one pass
         return launch_composite_quantize_u8(frames, img, mask, mask_is_float, mask_c, mask_n, out_u8, n, h * w, s);
     if (p.mask_only)        // only the mask needs its nearest resize: an index map, sampled in place by the same fused tail

@@ -108,8 +108,9 @@ double wino4_rounds_per_image(int H, int W, int cout);      // persistent-grid r
 // img: NCHW float [n][3][H][W], or (u8 != 0) HWC uint8 [n][H][W][3] converted as ToTensor does (v / 255)
 int launch_conv_first(const void* img, int u8, float* out_nhwc, const float* packed, const float* bias, int n, int H,
                       int W, hipStream_t s);
+// out_u8 != nullptr: the image is written as save_image's uint8 HWC [n][H][W][3] instead of NCHW float (out_nchw is then unused)
 int launch_conv_last(const float* in_nhwc, float* out_nchw, const float* packed, const float* bias, int n, int H,
-                     int W, hipStream_t s);
+                     int W, hipStream_t s, uint8_t* out_u8 = nullptr);
 
 // stats.hip
 int launch_mean_std(const float* feat, int nhwc, int n, int c, int hw, float eps, float* mean, float* std_,

@@ -304,8 +304,18 @@ __device__ __forceinline__ void static_for(F&& f) {
 // TH = tile height: 16 (612 halo pixels = 20 groups of 32, 5 per wave; T = 69 KB: two workgroups per CU; the product) or 12
 // (476 pixels = 15 groups, the fourth wave takes 3; T = 52 KB: three workgroups per CU; diagnostic library, ADAIN_CL_TH=12:
 // 64.3-64.5 us against 64.5-65.5 on the same box - the third workgroup buys nothing here, unlike in conv_first).
-template <int CLD, int TH>
-__global__ __launch_bounds__(256, TH == 12 ? 3 : 2) void conv_last_kernel(const float* __restrict__ in, float* __restrict__ out,
+// U8OUT (round 6): the image leaves as what torchvision's save_image makes of it (reference test.py:243-244) - x * 255 + 0.5, clamped to
+// [0, 255], truncated, uint8 HWC [n][H][W][3] - straight from the registers that hold the float pixel: adain_quantize_u8's arithmetic
+// operation for operation (the multiply and the add round separately: __fmul_rn / __fadd_rn, this file is compiled with contraction
+// on), so the bytes are those of conv_last + quantize_u8 (tests/test_gpu_stylize_u8.py: torch.equal) without the float image's
+// 12 + 12 bytes per pixel of HBM traffic and without the second launch.  adain_stylize_u8 without a mask ends with it.
+__device__ __forceinline__ unsigned cl_quant1(float x) {
+    float v = __fadd_rn(__fmul_rn(x, 255.0f), 0.5f);
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    return (unsigned)v;
+}
+template <int CLD, int TH, bool U8OUT = false>
+__global__ __launch_bounds__(256, TH == 12 ? 3 : 2) void conv_last_kernel(const float* __restrict__ in, void* __restrict__ out_any,
                                                                           const float* __restrict__ wpk, const float* __restrict__ bias,
                                                                           int H, int W, int tiles_x, int tiles_y) {
     constexpr int NPX = (TH + 2) * HW_, NGRP = (NPX + 31) / 32, GPW = (NGRP + 3) / 4, SLOTS = NGRP * 32;
@@ -389,10 +399,30 @@ __global__ __launch_bounds__(256, TH == 12 ? 3 : 2) void conv_last_kernel(const 
             }
         const int y = ty0 + yy, x = tx0 + ox;
         if (y < H && x < W) {
-            float* __restrict__ o = out + (size_t)img * 3 * H * W + (size_t)y * W + x;
-            o[0] = o0;
-            o[(size_t)H * W] = o1;
-            o[(size_t)2 * H * W] = o2;
+            if constexpr (U8OUT) {
+                // handled below: four neighbouring lanes' pixels leave as ONE 12-byte store (byte stores at a stride of 3 cost the
+                // kernel a third of its time)
+            } else {
+                float* __restrict__ o = (float*)out_any + (size_t)img * 3 * H * W + (size_t)y * W + x;
+                o[0] = o0;
+                o[(size_t)H * W] = o1;
+                o[(size_t)2 * H * W] = o2;
+            }
+        }
+        if constexpr (U8OUT) {
+            // this lane's pixel as 24 bits, then lane 4 q gathers the pixels of lanes 4 q .. 4 q + 3 (the same output row: a row is 32
+            // lanes) into three dwords; W is a multiple of 8 (the decoder's output is 8 hc x 8 wc) and the launcher checked the base
+            // pointer's alignment, so the 12 bytes sit on a dword boundary and a group of four pixels is inside the row or outside it
+            const unsigned w0 = cl_quant1(o0) | (cl_quant1(o1) << 8) | (cl_quant1(o2) << 16);
+            const unsigned w1 = __shfl_down(w0, 1), w2 = __shfl_down(w0, 2), w3 = __shfl_down(w0, 3);
+            if ((ox & 3) == 0 && y < H && x < W) {
+                using u32x3 = __attribute__((ext_vector_type(3))) unsigned;
+                u32x3 v;
+                v[0] = w0 | (w1 << 24);
+                v[1] = (w1 >> 8) | (w2 << 16);
+                v[2] = (w2 >> 16) | (w3 << 8);
+                *(u32x3*)((uint8_t*)out_any + (((size_t)img * H + y) * W + x) * 3) = v;
+            }
         }
     }
 }
@@ -450,8 +480,9 @@ int launch_conv_first(const void* img, int u8, float* out, const float* packed, 
     return check_launch("conv_first");
 }
 
-int launch_conv_last(const float* in, float* out, const float* packed, const float* bias, int n, int H, int W,
-                     hipStream_t s) {
+int launch_conv_last(const float* in, float* out_f32, const float* packed, const float* bias, int n, int H, int W,
+                     hipStream_t s, uint8_t* out_u8) {
+    void* const out = out_u8 ? (void*)out_u8 : (void*)out_f32;
     if (H < 2 || W < 2 || n < 1) { set_error("conv_last: H, W must be >= 2, got %dx%d", H, W); return -1; }
     if ((size_t)W * 256 * 18 >= 0x7ffffff0ULL) { set_error("conv_last: eighteen 64-channel rows of width %d reach 2 GiB", W); return -1; }
     int th = 16;
@@ -470,7 +501,9 @@ int launch_conv_last(const float* in, float* out, const float* packed, const flo
     else if (th == 12) hipLaunchKernelGGL((conv_last_kernel<0, 12>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
     else
 #endif
-    hipLaunchKernelGGL((conv_last_kernel<0, 16>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
+    if (out_u8 && ((W & 3) || ((uintptr_t)out_u8 & 3))) { set_error("conv_last: the uint8 form needs W %% 4 == 0 and a 4-byte aligned image"); return -1; }
+    if (out_u8) hipLaunchKernelGGL((conv_last_kernel<0, 16, true>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
+    else hipLaunchKernelGGL((conv_last_kernel<0, 16>), grid, dim3(256), 0, s, in, out, packed, bias, H, W, tx, ty);
     return check_launch("conv_last");
 }
 

@@ -205,7 +205,8 @@ ADAIN_API int adain_resize_pil_bilinear_u8(const uint8_t* in_u8, int pixel_bytes
  *                                                                        test.py:222-236  (adain_resize_* + adain_mask_composite)
  *     x*255 + 0.5, clamp, uint8 HWC                adain_quantize_u8      test.py:243-244
  * Every stage runs the kernel of the entry point named beside it with the same arguments, so `out_u8` holds the bytes that
- * sequence of calls gives; when decoder output and frame share one size (sides that are multiples of 8) the composite's passes
+ * sequence of calls gives; the tails are fused with the same arithmetic: without a mask the decoder's last layer quantises its
+ * pixels itself (no float image in HBM, no quantiser launch); when decoder output and frame share one size (sides that are multiples of 8) the composite's passes
  * and the quantiser run as ONE kernel with the same arithmetic - reading the mask in place when it has the frame's size too (a
  * mask made from the frame itself), sampling it with the nearest resize's index map when it has another (the guide loop: a view
  * resized to content_size with its mask at the view's own size, Style_3DGS/train.py:97-101).
@@ -213,7 +214,7 @@ ADAIN_API int adain_resize_pil_bilinear_u8(const uint8_t* in_u8, int pixel_bytes
  * image, once per style); depth_maps / depth_h / depth_w: HOST arrays of n device pointers / sizes; mask [mask_n][mask_c]
  * [mask_h][mask_w], mask_n in {1, n}, mask_c in {1, 3}, uint8 / bool bytes (mask_is_float == 0) or float; out_u8 HWC uint8
  * [n][oh][ow][3] with (oh, ow) = adain_stylize_u8_out_size: the frame's size with a mask, 8hc x 8wc without.  One workspace
- * (adain_stylize_u8_workspace_bytes) holds every intermediate.  ~27 kernel launches, no allocation, no synchronisation. */
+ * (adain_stylize_u8_workspace_bytes) holds every intermediate.  21-27 kernel launches, no allocation, no synchronisation. */
 ADAIN_API size_t adain_stylize_u8_workspace_bytes(int n, int h, int w, int use_depth, int mask_n, int mask_c, int mask_h, int mask_w,
                                         int mask_is_float);
 ADAIN_API void adain_stylize_u8_out_size(int h, int w, int has_mask, int* oh, int* ow);
