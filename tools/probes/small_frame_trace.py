@@ -55,7 +55,7 @@ def short(name):
 
 
 def is_call_start(k):
-    return k.startswith("conv_first_kernel<true>")
+    return k.startswith("conv_first_kernel<true")
 
 
 def report(d):
