@@ -19,6 +19,9 @@ sys.path.insert(0, ROOT)
 
 
 def run(h, w, nb, reps):
+    if os.environ.get("ADAIN_PROBE_DIAG_LIB"):      # A/B of a diagnostic-library switch (e.g. ADAIN_W4_PERSIST_ROUNDS_X10)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import _diag  # noqa: F401
     import torch
     import bench
     import applied_image_processing_amd.engine as engine_mod
