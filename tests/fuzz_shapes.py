@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """One-off shape fuzz on the GPU box: random content / style sizes and batches through style_transfer_simple / style_transfer and
 the decoder alone, against the CPU oracle: relative L2 <= 1e-4, the parity bar of both weight sets (tests/test_gpu_trained_like.py).
-One class of input is judged otherwise AND COUNTED: a case whose fp32 oracle is itself more than 3e-5 from its float64 run (frames of
-a few dozen pixels a side - a relu4_1 map of 10-50 positions: AdaIN divides by the standard deviation of a handful of samples and
-amplifies every fp32 path's rounding, this path's 3 x larger per-layer error more than the oracle's) must stay within 8 x the oracle's
-own distance and below 5e-4 (measured worst in 650 cases: 5.2 x, 3.2e-4); the summary line lists every such case, and more than 2 %
-of the cases fails the run.  Test infrastructure (it runs the oracle), not collected by pytest:
+The bar is hard for every case whose content AND style image have at least 48 pixels a side (the reference's defaults are 512 and
+256).  Below that - a relu4_1 map of a few dozen positions, where AdaIN divides by the standard deviation of a handful of samples and
+amplifies every fp32 path's rounding (the fp32 oracle's own distance from its float64 run reaches 7e-5 there, against 2.3e-5 on
+ordinary frames) - a case above the bar is judged by the float64 yardstick AND COUNTED: no further from the float64 oracle than 6 x
+the fp32 oracle itself is, and below 5e-4; the summary line lists every such case.  Measured over 800 trained-like cases (both
+schedules): 7 above 1e-4 (1.02e-4 ... 3.18e-4, at 2.0 - 5.2 x the oracle's own distance), every one of them with a side below
+48 pixels; the worst case with all sides >= 48: 9.3e-5.  With the Kaiming set no case is above 4e-6.  Test infrastructure (it runs the oracle), not collected by pytest:
     python tests/fuzz_shapes.py [n_cases] [seed] [kaiming|trained-like] [batch|latency]
 (`latency`: every call under ADAIN_SCHEDULE_LATENCY - the cin split of under-filled launches, which most of these small frames have)"""
 import os
@@ -28,7 +30,7 @@ KIND = sys.argv[3] if len(sys.argv) > 3 else "kaiming"
 SCHEDULE = sys.argv[4] if len(sys.argv) > 4 else "batch"
 rt.set_schedule(rt.SCHEDULE_LATENCY if SCHEDULE == "latency" else rt.SCHEDULE_BATCH)
 TOL = 1e-4
-ILL_FLOOR, ILL_FACTOR, ILL_CAP, ILL_SHARE = 3e-5, 8.0, 5e-4, 0.02
+SMALL_SIDE, YARD_FACTOR, YARD_CAP = 48, 6.0, 5e-4
 excused = []
 _v, _d = synth.state_dicts(KIND, 0)
 vgg_sd, dec_sd = synth.to_torch(_v), synth.to_torch(_d)
@@ -65,17 +67,17 @@ for case in range(n_cases):
     rel = float((got - ref).norm() / ref.norm())
     note = ""
     ok = rel <= TOL
-    if not ok and mode != 2:
+    if not ok and mode != 2 and min(h, w, hs, ws) < SMALL_SIDE:
         v64, d64 = {k: v.double() for k, v in vgg_sd.items()}, {k: v.double() for k, v in dec_sd.items()}
         with torch.no_grad():
             tru = (O.style_transfer_simple(v64, d64, c.double(), s.double(), alpha) if mode == 0 else
                    O.style_transfer(v64, d64, c.double(), s.double(), d.double(), 1.0, 0.2, 15))
         mine, floor = float((got.double() - tru).norm() / tru.norm()), float((ref.double() - tru).norm() / tru.norm())
-        ok = floor > ILL_FLOOR and mine <= ILL_FACTOR * floor and rel <= ILL_CAP
+        ok = mine <= YARD_FACTOR * floor and rel <= YARD_CAP
         note = f"   (the fp32 oracle itself is {floor:.2e} from float64, the HIP path {mine:.2e} = {mine / floor:.1f} x)"
         if ok:
             excused.append((case, rel, mine / floor))
-            note += "   ILL-CONDITIONED: judged by the float64 yardstick, counted"
+            note += f"   A SIDE BELOW {SMALL_SIDE} PIXELS: judged by the float64 yardstick, counted"
     else:
         worst = max(worst, rel)
     flag = note if ok and tuple(got.shape) == tuple(ref.shape) else note + "   <-- FAIL"
@@ -83,8 +85,5 @@ for case in range(n_cases):
     flag = "" if ok and tuple(got.shape) == tuple(ref.shape) else "FAIL"
     if flag:
         sys.exit(1)
-print(f"{KIND} weights, {SCHEDULE} schedule, {n_cases} cases, worst relative L2 {worst:.2e} (bar {TOL:g}); ill-conditioned cases judged by the float64 yardstick: "
+print(f"{KIND} weights, {SCHEDULE} schedule, {n_cases} cases, worst relative L2 {worst:.2e} (bar {TOL:g}, hard from {SMALL_SIDE} pixels a side); smaller cases above it, judged by the float64 yardstick: "
       f"{len(excused)} {[(c, float(f'{r:.3g}'), float(f'{x:.2g}')) for c, r, x in excused]}, {time.time() - t0:.0f} s")
-if len(excused) > ILL_SHARE * n_cases:
-    print("too many excused cases   <-- FAIL")
-    sys.exit(1)
