@@ -7,7 +7,7 @@ amplifies every fp32 path's rounding (the fp32 oracle's own distance from its fl
 ordinary frames) - a case above the bar is judged by the float64 yardstick AND COUNTED: no further from the float64 oracle than 6 x
 the fp32 oracle itself is, and below 5e-4; the summary line lists every such case.  Measured over 800 trained-like cases (both
 schedules): 7 above 1e-4 (1.02e-4 ... 3.18e-4, at 2.0 - 5.2 x the oracle's own distance), every one of them with a side below
-48 pixels; the worst case with all sides >= 48: 9.3e-5.  With the Kaiming set no case is above 4e-6.  Test infrastructure (it runs the oracle), not collected by pytest:
+48 pixels; the worst case with all sides >= 48: 9.0e-5.  With the Kaiming set no case is above 4e-6.  Test infrastructure (it runs the oracle), not collected by pytest:
     python tests/fuzz_shapes.py [n_cases] [seed] [kaiming|trained-like] [batch|latency]
 (`latency`: every call under ADAIN_SCHEDULE_LATENCY - the cin split of under-filled launches, which most of these small frames have)"""
 import os
